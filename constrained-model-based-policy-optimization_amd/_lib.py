@@ -1,0 +1,86 @@
+"""ctypes binding of the C-ABI in ``include/cmbpo_hip.h`` (libcmbpo_hip.so).
+
+This is the stub a maintainer of the reference would add:
+the reference has no FFI of its own, its hot path is TF ``sess.run`` + NumPy.
+The library is built in-tree by ``__graft_entry__.build()``; if it is missing
+the import of any product module fails loudly -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcmbpo_hip.so")
+
+ACT_SWISH, ACT_TANH = 0, 1
+HEAD_PROB, HEAD_DETMEAN, HEAD_GAUSS_PI = 0, 1, 2
+TASK_DEFAULT, TASK_HCS, TASK_ANTSAFE = 0, 1, 2
+
+# models/statics.py:56-69 -- task name -> rule id
+TASK_IDS = {
+    "default": TASK_DEFAULT,
+    "HalfCheetah-v2": TASK_DEFAULT,
+    "HalfCheetahSafe-v2": TASK_HCS,
+    "AntSafe-v2": TASK_ANTSAFE,
+}
+
+_p = C.c_void_p
+_i = C.c_int
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/cmbpo_hip.h declares.
+SIGNATURES = {
+    "cmbpo_last_error": (C.c_char_p, []),
+    "cmbpo_version": (_i, []),
+    "cmbpo_set_block_rows": (_i, [_i]),
+    "cmbpo_mlp_create": (_i, [C.POINTER(_p), _i, _i, _i, _i, _i, _i]),
+    "cmbpo_mlp_destroy": (None, [_p]),
+    "cmbpo_mlp_load": (_i, [_p] * 13),
+    "cmbpo_ens_forward": (_i, [_p, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p]),
+    "cmbpo_ens_predict_mean": (_i, [_p, _p, _i, _p, _p, _i, _p, _p]),
+    "cmbpo_policy_forward": (_i, [_p, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
+    "cmbpo_fakeenv_post": (_i, [_i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i,
+                                _p, _p, _p, _p, _p, _p, _p, _p]),
+}
+
+_lib = None
+
+
+class CmbpoHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CmbpoHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().cmbpo_last_error().decode("utf-8", "replace")
+        raise CmbpoHipError(f"{what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor / numpy array, None -> NULL."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,155 @@
+"""CPOPolicy -- host-side mirror of ``policies/cpo_policy.py:317-931`` for the hot path.
+
+Acting side (this file, rollout path):
+  ``get_action_outs(obs) -> {pi, logp_pi, pi_info{mu, log_std}, v, vc}`` (:801-823), ``get_v`` /
+  ``get_vc`` (:825-835), attributes ``pi_info_shapes``, ``gamma, lam, cost_gamma, cost_lam``
+  (:358-362; note the policy reads 'discount', not 'gamma'), ``agent.reward_penalized``.
+The actor is the tanh-MLP Gaussian policy of ``network/ac_network.py:99-123``; V and VC are
+3-member 'MSE' PE ensembles with in/out scalers (``policies/cpo_policy.py:452-468``).
+
+The update side (``update_policy`` / ``CPOAgent.update_pi``) lives in ``cpo_update.py``.
+All arithmetic is HIP behind the C-ABI; NumPy in -> NumPy out, CUDA tensors in -> CUDA tensors out.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .pens import PE, EnsembleMLP, _to_dev
+
+
+class GaussianActor:
+    """Parameters [W0,b0,W1,b1,W2,b2,log_std] (creation order of get_vars('pi'), ac_network.py:35-36)."""
+
+    def __init__(self, obs_dim, act_dim, hidden_sizes=(128, 128), device=None):
+        hidden_sizes = tuple(int(h) for h in hidden_sizes)
+        if len(hidden_sizes) != 2 or hidden_sizes[0] != hidden_sizes[1]:
+            raise ValueError("HIP actor supports two equal hidden layers; got %r" % (hidden_sizes,))
+        self.obs_dim, self.act_dim, self.hidden = int(obs_dim), int(act_dim), hidden_sizes[0]
+        self.mlp = EnsembleMLP(1, self.obs_dim, self.hidden, self.act_dim, "tanh", _lib.HEAD_GAUSS_PI, device)
+        self.device = self.mlp.device
+        self.shapes = [(obs_dim, self.hidden), (self.hidden,), (self.hidden, self.hidden), (self.hidden,),
+                       (self.hidden, act_dim), (act_dim,), (act_dim,)]
+        self.sizes = [int(np.prod(s)) for s in self.shapes]
+        self.n_params = int(sum(self.sizes))
+        self.params = None
+
+    def set_params(self, params):
+        """params: list of 7 arrays, or one flat vector in the same order (trust_region.py:21-25)."""
+        if not isinstance(params, (list, tuple)):
+            flat = np.asarray(params, dtype=np.float32).reshape(-1)
+            assert flat.size == self.n_params
+            params, off = [], 0
+            for shp, sz in zip(self.shapes, self.sizes):
+                params.append(flat[off:off + sz].reshape(shp))
+                off += sz
+        self.params = [np.ascontiguousarray(p, dtype=np.float32).reshape(s) for p, s in zip(params, self.shapes)]
+        w0, b0, w1, b1, w2, b2, ls = self.params
+        self.mlp.load([w0[None], w1[None], w2[None]], [b0[None], b1[None], b2[None]], log_std=ls)
+
+    def get_flat_params(self):
+        return np.concatenate([p.reshape(-1) for p in self.params]).astype(np.float32)
+
+    def forward_device(self, obs, eps, out, row_idx=None, n_rows=None):
+        n = obs.shape[0] if row_idx is None else (row_idx.shape[0] if n_rows is None else n_rows)
+        _lib.check(_lib.lib().cmbpo_policy_forward(
+            self.mlp.handle, _lib.ptr(obs), self.obs_dim, _lib.ptr(eps), _lib.ptr(row_idx), None, n,
+            _lib.ptr(out["pi"]), _lib.ptr(out["logp_pi"]), _lib.ptr(out["mu"]), _lib.ptr(out["log_std"]),
+            _lib.current_stream()), "cmbpo_policy_forward")
+        return out
+
+
+class _Agent:
+    """The attributes of CPOAgent the samplers read (policies/cpo_policy.py:105-108)."""
+    reward_penalized = False
+
+
+class CPOPolicy:
+    def __init__(self, obs_space, act_space, session=None, logger=None, device=None, seed=0, **kwargs):
+        self.obs_space, self.act_space = obs_space, act_space
+        self.obs_dim = int(np.prod(obs_space.shape))
+        self.act_dim = int(np.prod(act_space.shape))
+        kw = kwargs
+        self.hidden_sizes_a = kw.get("a_hidden_layer_sizes", (128, 128))
+        self.hidden_sizes_c = kw.get("vf_hidden_layer_sizes", (128, 128))
+        self.vf_ensemble = kw.get("vf_ensemble_size", 5)
+        self.vf_elites = kw.get("vf_elites", 3)
+        self.vf_activation = kw.get("vf_activation", "ReLU")
+        self.vf_loss = kw.get("vf_loss", "MSE")
+        if self.vf_activation != "swish" or self.vf_loss != "MSE":
+            raise NotImplementedError("HIP critics: vf_activation='swish', vf_loss='MSE' (every shipped config)")
+        self.ent_reg = kw.get("ent_reg", 0.0)
+        self.cost_lim = kw.get("cost_lim", 25)
+        self.constrain_cost = kw.get("constrain_cost", True)
+        self.target_kl = kw.get("target_kl", 0.01)
+        self.cost_lam = kw.get("cost_lam", 0.97)
+        self.cost_gamma = kw.get("cost_gamma", 0.99)
+        self.lam = kw.get("lam", 0.97)
+        self.gamma = kw.get("discount", 0.99)          # cpo_policy.py:362 reads 'discount'
+        self.max_path_length = kw.get("max_path_length", 1)
+        self.real_c_buffer = [self.cost_lim] * 300     # cpo_policy.py:356
+        self.logger = logger
+        self.agent = _Agent()
+        self.actor = GaussianActor(self.obs_dim, self.act_dim, self.hidden_sizes_a, device)
+        self.device = self.actor.device
+        common = dict(hidden_dims=self.hidden_sizes_c, num_networks=self.vf_ensemble,
+                      num_elites=self.vf_elites, loss="MSE", activation="swish",
+                      use_scaler_in=True, use_scaler_out=True, device=self.device)
+        self.v = PE(self.obs_dim, 1, name="VEnsemble", **common)
+        self.vc = PE(self.obs_dim, 1, name="VCEnsemble", **common)
+        # pi_info placeholders' shapes (network/ac_network.py:113,120; algorithms/cmbpo.py:94)
+        self.pi_info_shapes = {"mu": [self.act_dim], "log_std": [self.act_dim]}
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(int(seed))
+
+    def reset(self):
+        pass
+
+    def set_logger(self, logger):
+        self.logger = logger
+
+    # -- acting ----------------------------------------------------------------------------
+    def format_obs(self, obs):
+        if len(obs.shape) == len(self.obs_space.shape):
+            obs = obs[None]
+        return obs
+
+    def get_action_outs(self, obs, eps=None):
+        """policies/cpo_policy.py:801-823.  eps (optional) injects the N(0,1) draw of ac_network.py:109."""
+        obs = self.format_obs(obs)
+        if len(obs.shape) > 2:
+            raise NotImplementedError("bad observation shape")
+        with torch.cuda.device(self.device):
+            o, was_np = _to_dev(obs, self.device)
+            n = o.shape[0]
+            if eps is None:
+                e = torch.randn((n, self.act_dim), generator=self._gen, dtype=torch.float32, device=self.device)
+            else:
+                e, _ = _to_dev(eps, self.device)
+            f = dict(dtype=torch.float32, device=self.device)
+            out = dict(pi=torch.empty((n, self.act_dim), **f), logp_pi=torch.empty(n, **f),
+                       mu=torch.empty((n, self.act_dim), **f), log_std=torch.empty((n, self.act_dim), **f))
+            self.actor.forward_device(o, e, out)
+            v = self.v.predict(o)[:, 0]
+            vc = self.vc.predict(o)[:, 0]
+        res = {"pi": out["pi"], "logp_pi": out["logp_pi"],
+               "pi_info": {"mu": out["mu"], "log_std": out["log_std"]}, "v": v, "vc": vc}
+        if was_np:
+            res = {k: ({kk: vv.cpu().numpy() for kk, vv in val.items()} if isinstance(val, dict)
+                       else val.cpu().numpy()) for k, val in res.items()}
+        return res
+
+    def get_v(self, obs):
+        o = self.format_obs(obs)
+        r = self.v.predict(o)
+        return r[:, 0]
+
+    def get_vc(self, obs):
+        o = self.format_obs(obs)
+        r = self.vc.predict(o)
+        return r[:, 0]
+
+    def actions(self, obs):
+        return self.get_action_outs(obs)["pi"]
+
+    def actions_np(self, obs):
+        return np.array(self.actions(obs))

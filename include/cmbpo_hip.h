@@ -1,0 +1,137 @@
+/*
+ * cmbpo_hip.h -- C-ABI of the MI355X (gfx950) hot path for CMBPO.
+ *
+ * The reference (anyboby/Constrained-Model-Based-Policy-Optimization) is pure
+ * Python on TF 1.14 + NumPy: it has no FFI.  The "binding" a maintainer adds is
+ * therefore a ctypes stub; every entry point below names
+ * the reference Python interface (file:line, relative to the reference tree)
+ * whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative CMBPO_E* code otherwise;
+ *     cmbpo_last_error() returns a static, human-readable string for the last
+ *     failure on the calling thread.
+ *   - all pointers named d_* are DEVICE pointers owned by the caller (the
+ *     Python side allocates them as torch tensors); h_* are HOST pointers.
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on
+ *     that stream, nothing in here synchronises or allocates per call.
+ *   - handles own only packed weight copies; one host thread per handle.
+ *   - float is IEEE fp32; masks are uint8_t (0/1); indices are int32_t.
+ */
+#ifndef CMBPO_HIP_H
+#define CMBPO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMBPO_OK 0
+#define CMBPO_EINVAL (-1)   /* bad argument / unsupported shape            */
+#define CMBPO_EHIP (-2)     /* a HIP runtime call failed                   */
+#define CMBPO_ENOMEM (-3)   /* allocation failed                           */
+#define CMBPO_ESTATE (-4)   /* handle used before weights were loaded      */
+
+/* activations (models/pens/fc.py:13-20, network/ac_network.py:26-33) */
+#define CMBPO_ACT_SWISH 0
+#define CMBPO_ACT_TANH 1
+
+/* output heads */
+#define CMBPO_HEAD_PROB 0     /* mean|logvar split, models/pens/pe.py:789-838 */
+#define CMBPO_HEAD_DETMEAN 1  /* single head, mean over members, pe.py:338-343,648-669 */
+#define CMBPO_HEAD_GAUSS_PI 2 /* tanh-MLP Gaussian policy, network/ac_network.py:99-123 */
+
+/* static termination / cost rules (models/statics.py:56-69) */
+#define CMBPO_TASK_DEFAULT 0  /* no_done, zero (bool) cost: Hopper/Humanoid */
+#define CMBPO_TASK_HCS 1      /* HalfCheetahSafe-v2: no_done + hcs_cost_f    */
+#define CMBPO_TASK_ANTSAFE 2  /* AntSafe-v2: antsafe_term_fn + antsafe_c_fn  */
+
+const char *cmbpo_last_error(void);
+int cmbpo_version(void);
+
+/* Tuning knob (no reference counterpart): branches per workgroup of the 512-wide
+ * ensemble kernel, 32 (two workgroups per CU) or 64 (one, half the L2 weight traffic). */
+int cmbpo_set_block_rows(int rows);
+
+/* ------------------------------------------------------------------------ *
+ * Ensemble MLP handle: a 3-layer (in -> H -> H -> O) ensemble of E members.
+ * Replaces the TF variables of models/pens/pe.py:150-213 (PE.finalize: layers
+ * FC0..FC2 + TensorStandardScaler in/out) and, for HEAD_GAUSS_PI, the `pi`
+ * scope of network/ac_network.py:99-123 (dense x3 + log_std).
+ * ------------------------------------------------------------------------ */
+typedef struct cmbpo_mlp cmbpo_mlp_t;
+
+/* hidden must be 128 or 512.  out_width is the network's last-layer width
+ * (2*out_dim for HEAD_PROB, out_dim otherwise), <= 128. */
+int cmbpo_mlp_create(cmbpo_mlp_t **out, int ensemble, int in_dim, int hidden,
+                     int out_width, int activation, int head);
+void cmbpo_mlp_destroy(cmbpo_mlp_t *m);
+
+/* Weights in the reference's layout (models/pens/fc.py:135-166): W[E,in,out]
+ * row-major, b[E,out] (the reference's [E,1,out]).  Scaler vectors are the
+ * TensorStandardScaler mu/var ([1,dim], models/pens/utils.py:100-115); pass
+ * NULL for "no scaler".  h_log_std (HEAD_GAUSS_PI only) is the [out] vector of
+ * network/ac_network.py:104.  Packs on the host, copies on `stream`. */
+int cmbpo_mlp_load(cmbpo_mlp_t *m, const float *h_w0, const float *h_b0,
+                   const float *h_w1, const float *h_b1, const float *h_w2,
+                   const float *h_b2, const float *h_in_mu,
+                   const float *h_in_var, const float *h_out_mu,
+                   const float *h_out_var, const float *h_log_std,
+                   void *stream);
+
+/* PE.predict_ensemble, 2-D input path (models/pens/pe.py:688-697 ->
+ * _compile_outputs(scale_output=True) :789-838 -> FC.compute_output_tensor
+ * models/pens/fc.py:74-95 -> TensorStandardScaler models/pens/utils.py:156-187).
+ * x = [obs | act] per row (the concat of models/fake_env.py:81); d_act may be
+ * NULL with act_dim 0.  Row i of the call is branch d_row_idx[i] (or i when
+ * d_row_idx is NULL); d_n_rows (device int, may be NULL) overrides n_rows so a
+ * captured launch follows a device-side alive count.  Outputs are indexed
+ * [member][branch slot][out_dim] with leading dimension ld_rows. */
+int cmbpo_ens_forward(cmbpo_mlp_t *m, const float *d_obs, int obs_dim,
+                      const float *d_act, int act_dim, const int32_t *d_row_idx,
+                      const int32_t *d_n_rows, int n_rows, int ld_rows,
+                      float *d_mean, float *d_var, void *stream);
+
+/* PE.predict for the critics (models/pens/pe.py:648-669; mean over ALL members
+ * :338-343), as used by CPOPolicy.get_v/get_vc (policies/cpo_policy.py:825-835).
+ * d_out is [branch slot][out_dim]. */
+int cmbpo_ens_predict_mean(cmbpo_mlp_t *m, const float *d_obs, int obs_dim,
+                           const int32_t *d_row_idx, const int32_t *d_n_rows,
+                           int n_rows, float *d_out, void *stream);
+
+/* mlp_gaussian_policy forward (network/ac_network.py:99-123) behind
+ * CPOPolicy.get_action_outs (policies/cpo_policy.py:801-823): mu = MLP(obs),
+ * pi = mu + eps*exp(log_std), logp_pi = gaussian_likelihood(pi, mu, log_std)
+ * (:46-48).  eps is an input (the reference draws tf.random_normal, :109);
+ * outputs indexed by branch slot: d_pi,d_mu,d_logstd [.,act_dim], d_logp [.]. */
+int cmbpo_policy_forward(cmbpo_mlp_t *m, const float *d_obs, int obs_dim,
+                         const float *d_eps, const int32_t *d_row_idx,
+                         const int32_t *d_n_rows, int n_rows, float *d_pi,
+                         float *d_logp, float *d_mu, float *d_logstd,
+                         void *stream);
+
+/* FakeEnv.step after the ensemble forward (models/fake_env.py:104-151):
+ * std = sqrt(var); ens_ep_var = var_E(mean[..., :obs]); dkl_path = mean_d
+ * average_dkl(mean, std) (models/pens/utils.py:15-57, all E members);
+ * next_obs = mean[elite[b], b, :obs] + obs (delta model, deterministic=True);
+ * r = mean[elite[b], b, obs]; term / cost from models/statics.py evaluated on
+ * (obs, act, next_obs).  d_elite is the per-row member index (the draw of
+ * models/fake_env.py:174-178, injected by the caller).  Row addressing as in
+ * cmbpo_ens_forward.  d_cost is float (bool cast for the default task),
+ * d_term is uint8.  d_ep_var_mean = mean over obs dims of ens_ep_var (what
+ * samplers/model_sampler.py:322,343 consume); d_ep_var [.,obs_dim] optional. */
+int cmbpo_fakeenv_post(int task, int ensemble, int obs_dim, int act_dim,
+                       const float *d_mean, const float *d_var, int ld_rows,
+                       const float *d_obs, const float *d_act,
+                       const int32_t *d_elite, const int32_t *d_row_idx,
+                       const int32_t *d_n_rows, int n_rows, float *d_next_obs,
+                       float *d_rew, uint8_t *d_term, float *d_cost,
+                       float *d_dkl_path, float *d_ep_var_mean,
+                       float *d_ep_var, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMBPO_HIP_H */

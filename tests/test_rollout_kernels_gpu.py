@@ -1,0 +1,234 @@
+"""GPU parity: HIP rollout kernels (through the C-ABI) vs the CPU oracle on the same seeded inputs.
+
+Tolerances (fp32 path, stated per check):
+  * ensemble mean: |d| <= 2e-4 + 2e-4*|ref|  (K = 512 fp32 accumulations in a different order than
+    NumPy's BLAS; hidden activations O(1)),  var: rtol 2e-3 (exp of a logvar with the same abs error);
+  * policy / critic heads: 1e-4 abs+rel;
+  * FakeEnv post-processing on IDENTICAL (mean, var): next_obs / reward bit-exact (one fp32 add / a
+    copy), termination and cost masks bit-exact, dkl / variance rtol 1e-4 (device logf/expf vs libm).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import refcpu  # noqa: E402
+
+
+def _cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _dyn_model(rng, task, hidden=512, E=7):
+    from cmbpo_amd import synthetic
+    from cmbpo_amd.pens import PE
+    obs_dim, act_dim = synthetic.ENV_DIMS[task]
+    ws, bs = synthetic.ensemble_weights(rng, E, obs_dim + act_dim, hidden, 2 * (obs_dim + 1), bias_scale=0.05)
+    sc_in = synthetic.scaler(rng, obs_dim + act_dim)
+    sc_out = synthetic.scaler(rng, obs_dim + 1)
+    m = PE(obs_dim + act_dim, obs_dim + 1, hidden_dims=(hidden, hidden), num_networks=E, num_elites=5,
+           loss="MSPE", use_scaler_in=True, use_scaler_out=True, device="cuda:0")
+    m.set_weights(ws, bs, sc_in, sc_out)
+    return m, ws, bs, sc_in, sc_out, obs_dim, act_dim
+
+
+@pytest.mark.parametrize("task", ["AntSafe-v2", "HalfCheetahSafe-v2", "HopperSafe-v2", "HumanoidSafe-v2"])
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 257])
+def test_ens_forward_matches_oracle(hip_lib, task, n):
+    _cuda()
+    rng = np.random.default_rng(hash((task, n)) % 2**32)
+    m, ws, bs, sc_in, sc_out, obs_dim, act_dim = _dyn_model(rng, task)
+    x = rng.standard_normal((n, obs_dim + act_dim)).astype(np.float32)
+    mean, var = m.predict_ensemble(x)
+    rmean, rvar = refcpu.ens_forward(x, ws, bs, sc_in, sc_out)
+    assert mean.shape == rmean.shape == (7, n, obs_dim + 1)
+    np.testing.assert_allclose(mean, rmean, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(var, rvar, rtol=2e-3, atol=1e-7)
+
+
+def test_ens_forward_no_scalers_hidden128(hip_lib):
+    _cuda()
+    from cmbpo_amd import synthetic
+    from cmbpo_amd.pens import PE
+    rng = np.random.default_rng(5)
+    E, I, O = 3, 26, 21
+    ws, bs = synthetic.ensemble_weights(rng, E, I, 128, 2 * O, bias_scale=0.1)
+    m = PE(I, O, hidden_dims=(128, 128), num_networks=E, num_elites=2, loss="MSPE", device="cuda:0")
+    m.set_weights(ws, bs)
+    x = rng.standard_normal((100, I)).astype(np.float32)
+    mean, var = m.predict_ensemble(x)
+    rmean, rvar = refcpu.ens_forward(x, ws, bs)
+    np.testing.assert_allclose(mean, rmean, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(var, rvar, rtol=1e-3, atol=1e-7)
+
+
+def test_ens_forward_row_gather_and_split_inputs(hip_lib):
+    """obs/act passed separately, rows addressed through an index list into branch slots."""
+    dev = _cuda()
+    rng = np.random.default_rng(11)
+    m, ws, bs, sc_in, sc_out, obs_dim, act_dim = _dyn_model(rng, "AntSafe-v2")
+    B = 300
+    obs = rng.standard_normal((B, obs_dim)).astype(np.float32)
+    act = rng.standard_normal((B, act_dim)).astype(np.float32)
+    idx = np.sort(rng.choice(B, size=77, replace=False)).astype(np.int32)
+    mean = torch.full((7, B, obs_dim + 1), float("nan"), device=dev)
+    var = torch.full((7, B, obs_dim + 1), float("nan"), device=dev)
+    m.predict_ensemble(torch.from_numpy(obs).to(dev), act=torch.from_numpy(act).to(dev),
+                       row_idx=torch.from_numpy(idx).to(dev), out=(mean, var))
+    rmean, rvar = refcpu.ens_forward(np.concatenate([obs, act], -1)[idx], ws, bs, sc_in, sc_out)
+    got = mean.cpu().numpy()
+    np.testing.assert_allclose(got[:, idx], rmean, rtol=2e-4, atol=2e-4)
+    untouched = np.setdiff1d(np.arange(B), idx)
+    assert np.isnan(got[:, untouched]).all()     # rows outside the list are never written
+
+
+@pytest.mark.parametrize("n", [1, 32, 100, 1000])
+def test_critic_predict_mean(hip_lib, n):
+    _cuda()
+    from cmbpo_amd import synthetic
+    from cmbpo_amd.pens import PE
+    rng = np.random.default_rng(n)
+    E, obs_dim = 3, 29
+    ws, bs = synthetic.ensemble_weights(rng, E, obs_dim, 128, 1, bias_scale=0.1)
+    sc_in, sc_out = synthetic.scaler(rng, obs_dim), synthetic.scaler(rng, 1, hit_clamp=False)
+    v = PE(obs_dim, 1, hidden_dims=(128, 128), num_networks=E, num_elites=2, loss="MSE",
+           use_scaler_in=True, use_scaler_out=True, device="cuda:0")
+    v.set_weights(ws, bs, sc_in, sc_out)
+    x = rng.standard_normal((n, obs_dim)).astype(np.float32)
+    got = v.predict(x)
+    ref = refcpu.ens_predict_mean(x, ws, bs, sc_in, sc_out)
+    assert got.shape == ref.shape == (n, 1)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("task", ["AntSafe-v2", "HumanoidSafe-v2", "HopperSafe-v2"])
+def test_policy_forward(hip_lib, task):
+    _cuda()
+    from cmbpo_amd import synthetic
+    from cmbpo_amd.cpo_policy import GaussianActor
+    rng = np.random.default_rng(3)
+    obs_dim, act_dim = synthetic.ENV_DIMS[task]
+    params = synthetic.policy_params(rng, obs_dim, act_dim)
+    params[1] = (rng.standard_normal(128) * 0.1).astype(np.float32)
+    params[5] = (rng.standard_normal(act_dim) * 0.1).astype(np.float32)
+    params[6] = rng.uniform(-1.0, 0.0, act_dim).astype(np.float32)
+    actor = GaussianActor(obs_dim, act_dim, (128, 128), device="cuda:0")
+    actor.set_params(params)
+    n = 333
+    obs = rng.standard_normal((n, obs_dim)).astype(np.float32)
+    eps = rng.standard_normal((n, act_dim)).astype(np.float32)
+    dev = actor.device
+    f = dict(dtype=torch.float32, device=dev)
+    out = dict(pi=torch.empty((n, act_dim), **f), logp_pi=torch.empty(n, **f),
+               mu=torch.empty((n, act_dim), **f), log_std=torch.empty((n, act_dim), **f))
+    actor.forward_device(torch.from_numpy(obs).to(dev), torch.from_numpy(eps).to(dev), out)
+    ref = refcpu.policy_forward(obs, params, eps)
+    for k in ("pi", "mu", "logp_pi", "log_std"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=1e-4, atol=1e-4, err_msg=k)
+    np.testing.assert_array_equal(out["log_std"].cpu().numpy(), ref["log_std"])
+
+
+def _post_inputs(rng, task, n, E=7):
+    from cmbpo_amd import synthetic
+    obs_dim, act_dim = synthetic.ENV_DIMS[task]
+    obs = synthetic.start_states(rng, n, task)
+    act = rng.uniform(-1, 1, (n, act_dim)).astype(np.float32)
+    mean = (rng.standard_normal((E, n, obs_dim + 1)) * 0.3).astype(np.float32)
+    var = np.exp(rng.uniform(-12, 1, (E, n, obs_dim + 1))).astype(np.float32)
+    var[:, ::7, 3] = 0.0                                   # std = 0 -> log clip at -100
+    var[:, 1::11, 5] = np.float32(1e-30)
+    inds = rng.choice(np.array([0, 2, 3, 5, 6], np.int32), size=n)
+    return obs_dim, act_dim, obs, act, mean, var, inds.astype(np.int32)
+
+
+def _run_post(task, obs, act, mean, var, inds, obs_dim, act_dim):
+    from cmbpo_amd import _lib
+    dev = torch.device("cuda:0")
+    n, E = obs.shape[0], mean.shape[0]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    f = dict(dtype=torch.float32, device=dev)
+    out = dict(next_obs=torch.empty((n, obs_dim), **f), rew=torch.empty(n, **f),
+               term=torch.empty(n, dtype=torch.uint8, device=dev), cost=torch.empty(n, **f),
+               dkl_path=torch.empty(n, **f), ep_var_mean=torch.empty(n, **f),
+               ep_var=torch.empty((n, obs_dim), **f))
+    d = [t(obs), t(act), t(mean), t(var), t(inds)]
+    _lib.check(_lib.lib().cmbpo_fakeenv_post(
+        _lib.TASK_IDS.get(task, 0), E, obs_dim, act_dim, _lib.ptr(d[2]), _lib.ptr(d[3]), n,
+        _lib.ptr(d[0]), _lib.ptr(d[1]), _lib.ptr(d[4]), None, None, n,
+        _lib.ptr(out["next_obs"]), _lib.ptr(out["rew"]), _lib.ptr(out["term"]), _lib.ptr(out["cost"]),
+        _lib.ptr(out["dkl_path"]), _lib.ptr(out["ep_var_mean"]), _lib.ptr(out["ep_var"]),
+        _lib.current_stream()), "cmbpo_fakeenv_post")
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("task", ["AntSafe-v2", "HalfCheetahSafe-v2", "HopperSafe-v2", "HumanoidSafe-v2"])
+@pytest.mark.parametrize("n", [1, 8, 1001])
+def test_fakeenv_post_matches_oracle(hip_lib, task, n):
+    _cuda()
+    rng = np.random.default_rng(hash((task, n, "post")) % 2**32)
+    obs_dim, act_dim, obs, act, mean, var, inds = _post_inputs(rng, task, n)
+    if task == "AntSafe-v2" and n > 8:
+        # force every branch of the termination rule, incl. the precedence quirk and non-finite rows
+        mean[:, 0, 0] = 5.0       # z > 1           -> gate 0 -> not done
+        mean[:, 1, 0] = -5.0      # z < 0.2         -> gate 0 -> not done
+        mean[:, 2, 2] = 2.0       # z_rot << -0.7, gate 1 (z ok) -> done
+        obs[2, 0] = 0.5; mean[:, 2, 0] = 0.0
+        mean[:, 3, 4] = np.nan    # non-finite, z_rot finite -> gate 0 -> not done
+        mean[:, 4, 2] = np.inf    # z_rot = -inf, gate 0 -> 0 * -inf = nan -> done
+        mean[:, 5, -2] = 10.0     # |y| > 3.2 -> cost 1 (obs slot is out_dim-2 = obs_dim-1)
+    got = _run_post(task, obs, act, mean, var, inds, obs_dim, act_dim)
+    with np.errstate(all="ignore"):
+        rn, rr, rt, info = refcpu.fake_env_step(obs, act, mean, var, inds, task)
+    np.testing.assert_array_equal(got["next_obs"], rn)                       # bit-exact
+    np.testing.assert_array_equal(got["rew"], rr[:, 0])                      # bit-exact
+    np.testing.assert_array_equal(got["term"].astype(bool), rt[:, 0])        # bit-exact masks
+    np.testing.assert_array_equal(got["cost"], np.asarray(info["cost"], np.float32)[:, 0])
+    ok = np.isfinite(info["ensemble_dkl_path"])
+    np.testing.assert_allclose(got["dkl_path"][ok], info["ensemble_dkl_path"][ok], rtol=1e-4, atol=1e-7)
+    evar = info["ensemble_ep_var"]
+    okv = np.isfinite(evar)
+    np.testing.assert_allclose(got["ep_var"][okv], evar[okv], rtol=1e-5, atol=1e-9)
+    okm = np.isfinite(evar).all(-1)
+    np.testing.assert_allclose(got["ep_var_mean"][okm], evar.mean(-1)[okm], rtol=1e-5, atol=1e-9)
+    if task == "AntSafe-v2" and n > 8:
+        assert list(got["term"][:5]) == [0, 0, 1, 0, 1]
+
+
+def test_fake_env_step_end_to_end(hip_lib):
+    """FakeEnv.step (HIP forward + post) vs oracle forward + oracle step; masks must be consistent
+    with the kernel's own next_obs (bit-exact rule evaluation)."""
+    _cuda()
+    from cmbpo_amd.fake_env import FakeEnv
+    rng = np.random.default_rng(21)
+    task = "AntSafe-v2"
+    m, ws, bs, sc_in, sc_out, obs_dim, act_dim = _dyn_model(rng, task)
+
+    class _Space:
+        def __init__(self, d):
+            self.shape = (d,)
+
+    class _Env:
+        observation_space, action_space = _Space(obs_dim), _Space(act_dim)
+
+    env = FakeEnv(_Env(), task, m, predicts_delta=True, predicts_rew=True, predicts_cost=False)
+    from cmbpo_amd import synthetic
+    n = 500
+    obs = synthetic.start_states(rng, n, task)
+    act = rng.uniform(-1, 1, (n, act_dim)).astype(np.float32)
+    inds = rng.choice(np.asarray(m.elite_inds, np.int32), size=n).astype(np.int32)
+    nobs, r, terms, info = env.step(obs, act, model_inds=inds)
+    rmean, rvar = refcpu.ens_forward(np.concatenate([obs, act], -1), ws, bs, sc_in, sc_out)
+    rn, rr, rt, rinfo = refcpu.fake_env_step(obs, act, rmean, rvar, inds, task)
+    assert nobs.shape == (n, obs_dim) and r.shape == (n, 1) and terms.shape == (n, 1) and terms.dtype == bool
+    np.testing.assert_allclose(nobs, rn, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(r, rr, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(info["ensemble_dkl_path"], rinfo["ensemble_dkl_path"], rtol=5e-3, atol=1e-6)
+    np.testing.assert_allclose(info["ensemble_ep_var"], rinfo["ensemble_ep_var"], rtol=5e-3, atol=1e-7)
+    # rules re-evaluated by the oracle on the kernel's own next_obs: bit-exact
+    np.testing.assert_array_equal(terms, refcpu.antsafe_term_fn(obs, act, nobs))
+    np.testing.assert_array_equal(info["cost"], refcpu.antsafe_c_fn(obs, act, nobs).astype(np.float32))

@@ -42,6 +42,44 @@ SIGNATURES = {
                                 _p, _p, _p, _p, _p, _p, _p, _p]),
 }
 
+
+
+class RolloutStruct(C.Structure):
+    """ctypes image of ``cmbpo_rollout_t`` (include/cmbpo_hip.h), field for field."""
+    _fields_ = (
+        [(n, C.c_int32) for n in ("B", "T", "obs_dim", "act_dim", "max_path_length", "ptr",
+                                  "uncertainty_mode", "rank", "world")]
+        + [("max_samples", C.c_int64), ("dkl_lim", C.c_double), ("gamma", C.c_double), ("lam", C.c_double),
+           ("cost_gamma", C.c_double), ("cost_lam", C.c_double)]
+        + [(n, C.c_void_p) for n in (
+            "alive_idx", "alive_idx_out", "iscal", "dscal", "g_counts", "alive", "fin_code", "len",
+            "cur_obs", "next_obs", "act_t", "logp_t", "mu_t", "ls_t", "v_t", "vc_t", "v_n", "vc_n",
+            "rew_t", "cost_t", "dkl_t", "epv_t", "term_t",
+            "dkl_acc", "path_ret", "path_cost", "path_dyn_var",
+            "obs_buf", "act_buf", "mu_buf", "ls_buf",
+            "rew_buf", "val_buf", "cost_buf", "cval_buf", "logp_buf",
+            "adv_buf", "ret_buf", "cadv_buf", "cret_buf")]
+    )
+
+
+# iscal / dscal slots (CMBPO_I_* / CMBPO_D_* in the header)
+I_N_ALIVE, I_N_UNC, I_N_FIN_PRE, I_N_STORED, I_N_ALIVE_OUT, I_SIZE = 0, 1, 2, 3, 4, 5
+(D_TOTAL_SAMPLES, D_TOTAL_COST, D_TOTAL_REW, D_TOTAL_VS, D_TOTAL_CVS, D_TOTAL_DKL, D_TOTAL_DYN_EP_VAR,
+ D_MAX_DKL, D_MAX_PATH_RETURN, D_DKL_SUM_T, D_STEP_MAX_DKL, D_SUM_PATH_RET, D_SUM_PATH_COST) = range(13)
+
+_rp = C.POINTER(RolloutStruct)
+SIGNATURES.update({
+    "cmbpo_rollout_reset": (_i, [_rp, _p]),
+    "cmbpo_rollout_decide": (_i, [_rp, _p]),
+    "cmbpo_rollout_count": (_i, [_rp, _p]),
+    "cmbpo_rollout_finish": (_i, [_rp, _i, _p]),
+    "cmbpo_rollout_store": (_i, [_rp, _p]),
+    "cmbpo_rollout_compact": (_i, [_rp, _p]),
+    "cmbpo_buffer_offsets": (_i, [_rp, _p, _p]),
+    "cmbpo_buffer_moments": (_i, [_rp, _i, _p, _p]),
+    "cmbpo_buffer_flatten": (_i, [_rp, _p, _p, C.POINTER(C.c_void_p), _p]),
+})
+
 _lib = None
 
 

@@ -1,0 +1,594 @@
+// Device-resident rollout bookkeeping: the fused counterpart of
+//   samplers/model_sampler.py:239-444  (ModelSampler.sample / _finish_paths / finish_all_paths)
+//   buffers/modelbuffer.py:53-226      (ModelBuffer.reset / store_multiple / finish_path_multiple / get)
+//   utilities/utils.py:184-188         (discount_cumsum, un-weighted branch: lfilter([1],[1,-g*l]) in float64)
+//   utilities/mpi_tools.py:71-92       (mpi_statistics_scalar: two-pass mean / std)
+//
+// All kernels here are HBM / latency bound integer-and-scan work: branch slots never move, an ordered
+// alive list replaces the reference's per-step boolean-mask compaction, and the (T, B) time-major
+// buffers make both the per-step store and the per-branch backward GAE recurrence coalesced
+// (adjacent lanes = adjacent branches).
+#include "common.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int kScanThreads = 1024;
+
+// ---- block-level helpers (wave = 64 lanes) -----------------------------------------------------
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// exclusive scan over the block (blockDim.x <= 1024); *total = block sum.  `sm` needs 17 ints.
+__device__ __forceinline__ int block_excl_scan(int v, int *sm, int *total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const int inc = wave_incl_scan(v, lane);
+  __syncthreads();  // sm reuse across calls
+  if (lane == 63) sm[w] = inc;
+  __syncthreads();
+  if (w == 0) {
+    int t = (lane < nw) ? sm[lane] : 0;
+    t = wave_incl_scan(t, lane);
+    if (lane < nw) sm[lane] = t;
+    if (lane == nw - 1) sm[16] = t;
+  }
+  __syncthreads();
+  *total = sm[16];
+  return inc - v + (w > 0 ? sm[w - 1] : 0);
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+  return v;
+}
+
+// block sum; result valid in thread 0.  `sm` needs 16 doubles.
+__device__ __forceinline__ double block_sum(double v, double *sm) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (w == 0) {
+    t = (lane < nw) ? sm[lane] : 0.0;
+    t = wave_sum(t);
+  }
+  return t;
+}
+
+__device__ __forceinline__ double block_max(double v, double *sm) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_max(v);
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (w == 0) {
+    t = (lane < nw) ? sm[lane] : -1e300;
+    t = wave_max(t);
+  }
+  return t;
+}
+
+// max for non-negative doubles through their (monotone) bit pattern
+__device__ __forceinline__ void atomic_max_nonneg(double *addr, double v) {
+  if (!(v > 0.0)) return;
+  atomicMax(reinterpret_cast<unsigned long long *>(addr),
+            static_cast<unsigned long long>(__double_as_longlong(v)));
+}
+
+// ---- reset -------------------------------------------------------------------------------------
+__global__ void reset_kernel(const cmbpo_rollout_t r) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < r.B) {
+    r.alive[b] = 1;
+    r.fin_code[b] = 0;
+    r.len[b] = 0;
+    r.alive_idx[b] = b;
+    r.dkl_acc[b] = 0.0;
+    r.path_ret[b] = 0.0;
+    r.path_cost[b] = 0.0;
+    r.path_dyn_var[b] = 0.0;
+  }
+  if (b < 32) {
+    r.iscal[b] = (b == CMBPO_I_N_ALIVE) ? r.B : 0;
+    r.dscal[b] = 0.0;
+  }
+}
+
+// ---- decide: uncertainty test + budget early termination (model_sampler.py:275-287) ------------
+__device__ __forceinline__ bool too_uncertain(const cmbpo_rollout_t &r, int b) {
+  // next_dkl = _dyn_dkl_path[alive] (float64) + dyn_dkl_path (float32) >= dkl_lim
+  return r.uncertainty_mode && (r.dkl_acc[b] + (double)r.dkl_t[b] >= r.dkl_lim);
+}
+
+__global__ __launch_bounds__(kScanThreads) void decide_kernel(const cmbpo_rollout_t r, int count_only) {
+  __shared__ int sm_i[17];
+  __shared__ double sm_d[16];
+  __shared__ long long s_excess;
+  __shared__ int s_rank_off;
+  const int tid = threadIdx.x;
+  const int n = r.iscal[CMBPO_I_N_ALIVE];
+
+  int cnt = 0;
+  double dsum = 0.0;
+  for (int i = tid; i < n; i += kScanThreads) {
+    const int b = r.alive_idx[i];
+    cnt += too_uncertain(r, b) ? 1 : 0;
+    dsum += (double)r.dkl_t[b];
+  }
+  const double n_unc_d = block_sum((double)cnt, sm_d);
+  const double dkl_sum = block_sum(dsum, sm_d);
+  if (tid == 0) {
+    const int n_unc = (int)n_unc_d;
+    r.iscal[CMBPO_I_N_UNC] = n_unc;
+    r.dscal[CMBPO_D_DKL_SUM_T] = dkl_sum;
+    // the row other shards gather: {n_alive, n_unc, total_samples, 0}
+    r.iscal[8] = n;
+    r.iscal[9] = n_unc;
+    r.iscal[10] = (int)r.dscal[CMBPO_D_TOTAL_SAMPLES];
+    r.iscal[11] = 0;
+    long long excess = 0;
+    int rank_off = 0;
+    if (r.max_samples > 0) {
+      long long tot = (long long)r.dscal[CMBPO_D_TOTAL_SAMPLES], g_n = n, g_unc = n_unc;
+      if (r.g_counts) {
+        tot = 0; g_n = 0; g_unc = 0;
+        for (int q = 0; q < r.world; ++q) {
+          g_n += r.g_counts[4 * q + 0];
+          g_unc += r.g_counts[4 * q + 1];
+          tot += r.g_counts[4 * q + 2];
+          if (q < r.rank) rank_off += r.g_counts[4 * q + 0] - r.g_counts[4 * q + 1];
+        }
+      }
+      // n = total + alive - too_uncertain; n = max(n - max_samples, 0)
+      excess = tot + g_n - g_unc - (long long)r.max_samples;
+      if (excess < 0) excess = 0;
+    }
+    s_excess = excess;
+    s_rank_off = rank_off;
+  }
+  __syncthreads();
+  if (count_only) return;
+  const long long excess = s_excess;
+  const int rank_off = s_rank_off;
+
+  int carry = 0, nfin = 0;
+  for (int base = 0; base < n; base += kScanThreads) {
+    const int i = base + tid;
+    int b = -1;
+    bool unc = false;
+    if (i < n) {
+      b = r.alive_idx[i];
+      unc = too_uncertain(r, b);
+    }
+    const int flag = (i < n && !unc) ? 1 : 0;
+    int total;
+    const int excl = block_excl_scan(flag, sm_i, &total);
+    if (i < n) {
+      // early_term[:n] = True over the surviving rows in index order
+      const bool early = flag && ((long long)rank_off + carry + excl < excess);
+      const uint8_t code = (unc || early) ? 1 : 0;
+      r.fin_code[b] = code;
+      nfin += code;
+    }
+    carry += total;
+  }
+  const double nf = block_sum((double)nfin, sm_d);
+  if (tid == 0) r.iscal[CMBPO_I_N_FIN_PRE] = (int)nf;
+}
+
+// ---- finish: reward + cost GAE, then mark terminated (modelbuffer.py:138-182) -------------------
+__global__ __launch_bounds__(256) void finish_kernel(const cmbpo_rollout_t r, int mode) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = r.iscal[CMBPO_I_N_ALIVE];
+  if (i >= n) return;
+  const int b = r.alive_idx[i];
+  float lv, lcv;
+  bool zero_boot = false;
+  if (mode == 0) {
+    const uint8_t code = r.fin_code[b];
+    if (!code) return;
+    lv = r.v_t[b];
+    lcv = r.vc_t[b];
+    if (code == 2) {  // finish_path_multiple called with float64 zeros as last_val
+      lv = 0.0f;
+      zero_boot = true;
+    }
+  } else if (mode == 1) {
+    if (r.fin_code[b]) return;  // finished before the store
+    // path_length (= ptr + 1 after the store) >= max_path_length - 1, model_sampler.py:352
+    const bool horizon = (r.ptr + 1 >= r.max_path_length - 1);
+    if (horizon) {
+      lv = r.v_n[b];
+    } else if (r.term_t[b]) {
+      lv = 0.0f;
+      zero_boot = true;  // np.zeros -> float64 rews/vals in the reference (model_sampler.py:404)
+    } else {
+      return;
+    }
+    lcv = r.vc_n[b];  // terminal branches still bootstrap the cost value (:364)
+  } else {
+    if (!r.alive[b]) return;
+    lv = r.v_t[b];
+    lcv = r.vc_t[b];
+  }
+  const int L = r.len[b];
+  const size_t B = (size_t)r.B;
+  const float g32 = (float)r.gamma, cg32 = (float)r.cost_gamma;
+  const double gl = r.gamma * r.lam, cgl = r.cost_gamma * r.cost_lam;
+  double y = 0.0, cy = 0.0;
+  float vnext = lv, cvnext = lcv;
+  for (int t = L - 1; t >= 0; --t) {
+    const size_t o = (size_t)t * B + b;
+    const float rw = r.rew_buf[o], v = r.val_buf[o], c = r.cost_buf[o], cv = r.cval_buf[o];
+    double delta;
+    if (zero_boot) {
+      // float64 arithmetic: rews/vals were promoted by the float64 zeros bootstrap
+      delta = __dsub_rn(__dadd_rn((double)rw, __dmul_rn(r.gamma, (double)vnext)), (double)v);
+    } else {
+      delta = (double)__fsub_rn(__fadd_rn(rw, __fmul_rn(g32, vnext)), v);
+    }
+    const float cdelta = __fsub_rn(__fadd_rn(c, __fmul_rn(cg32, cvnext)), cv);
+    // lfilter([1], [1, -g*l]) on the reversed row, float64 state: y = x + (g*l)*y_prev
+    y = __dadd_rn(delta, __dmul_rn(gl, y));
+    cy = __dadd_rn((double)cdelta, __dmul_rn(cgl, cy));
+    const float adv = (float)y, cadv = (float)cy;
+    r.adv_buf[o] = adv;
+    r.ret_buf[o] = __fadd_rn(adv, v);
+    r.cadv_buf[o] = cadv;
+    r.cret_buf[o] = __fadd_rn(cadv, cv);
+    vnext = v;
+    cvnext = cv;
+  }
+  r.alive[b] = 0;
+}
+
+// ---- store: transition -> column ptr, sampler accumulators ---------------------------------------
+constexpr int kStoreRows = 64;  // rows per workgroup (limits same-address atomics)
+
+__global__ __launch_bounds__(256) void store_kernel(const cmbpo_rollout_t r) {
+  __shared__ double sm_d[16];
+  const int n = r.iscal[CMBPO_I_N_ALIVE];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * kStoreRows;
+  if (row0 >= n) return;
+  const size_t B = (size_t)r.B;
+  const int D = r.obs_dim, A = r.act_dim;
+  const int width = D + 3 * A;
+  const double dkl_mean = r.dscal[CMBPO_D_DKL_SUM_T] / (double)n;  // np.mean over the rows stepped
+  double a_cnt = 0, a_cost = 0, a_rew = 0, a_v = 0, a_vc = 0, a_epv = 0, a_maxdkl = 0, a_maxret = 0;
+  for (int k = w; k < kStoreRows; k += 4) {
+    const int i = row0 + k;
+    if (i >= n) break;
+    const int b = r.alive_idx[i];
+    if (r.fin_code[b]) continue;
+    const size_t col = (size_t)r.ptr * B + b;
+    for (int e = lane; e < width; e += 64) {
+      if (e < D) {
+        r.obs_buf[col * D + e] = r.cur_obs[(size_t)b * D + e];
+      } else if (e < D + A) {
+        r.act_buf[col * A + (e - D)] = r.act_t[(size_t)b * A + (e - D)];
+      } else if (e < D + 2 * A) {
+        r.mu_buf[col * A + (e - D - A)] = r.mu_t[(size_t)b * A + (e - D - A)];
+      } else {
+        r.ls_buf[col * A + (e - D - 2 * A)] = r.ls_t[(size_t)b * A + (e - D - 2 * A)];
+      }
+    }
+    if (lane == 0) {
+      const float rw = r.rew_t[b], c = r.cost_t[b], v = r.v_t[b], vc = r.vc_t[b];
+      const float epv = r.epv_t[b], dk = r.dkl_t[b];
+      r.rew_buf[col] = rw;
+      r.val_buf[col] = v;
+      r.cost_buf[col] = c;
+      r.cval_buf[col] = vc;
+      r.logp_buf[col] = r.logp_t[b];
+      r.len[b] = r.ptr + 1;
+      const double pr = r.path_ret[b] + (double)rw;
+      r.path_ret[b] = pr;
+      r.path_cost[b] += (double)c;
+      r.path_dyn_var[b] += (double)epv;
+      r.dkl_acc[b] += (double)dk;
+      a_cnt += 1.0; a_cost += c; a_rew += rw; a_v += v; a_vc += vc;
+      a_epv += (double)epv * D;
+      a_maxdkl = fmax(a_maxdkl, (double)dk);
+      a_maxret = fmax(a_maxret, pr);
+    }
+  }
+  // lane 0 of each wave holds partials; reduce the 4 waves through LDS
+  const double cnt = block_sum(a_cnt, sm_d);
+  const double cost = block_sum(a_cost, sm_d);
+  const double rew = block_sum(a_rew, sm_d);
+  const double sv = block_sum(a_v, sm_d);
+  const double svc = block_sum(a_vc, sm_d);
+  const double epv = block_sum(a_epv, sm_d);
+  const double mdkl = block_max(a_maxdkl, sm_d);
+  const double mret = block_max(a_maxret, sm_d);
+  if (threadIdx.x == 0 && cnt > 0.0) {
+    atomicAdd(&r.iscal[CMBPO_I_N_STORED], (int)cnt);
+    atomicAdd(&r.iscal[CMBPO_I_SIZE], (int)cnt);
+    atomicAdd(&r.dscal[CMBPO_D_TOTAL_SAMPLES], cnt);
+    atomicAdd(&r.dscal[CMBPO_D_TOTAL_COST], cost);
+    atomicAdd(&r.dscal[CMBPO_D_TOTAL_REW], rew);
+    atomicAdd(&r.dscal[CMBPO_D_SUM_PATH_RET], rew);
+    atomicAdd(&r.dscal[CMBPO_D_SUM_PATH_COST], cost);
+    atomicAdd(&r.dscal[CMBPO_D_TOTAL_VS], sv);
+    atomicAdd(&r.dscal[CMBPO_D_TOTAL_CVS], svc);
+    atomicAdd(&r.dscal[CMBPO_D_TOTAL_DYN_EP_VAR], epv);
+    atomicAdd(&r.dscal[CMBPO_D_TOTAL_DKL], dkl_mean * cnt);
+    atomic_max_nonneg(&r.dscal[CMBPO_D_MAX_DKL], mdkl);
+    atomic_max_nonneg(&r.dscal[CMBPO_D_MAX_PATH_RETURN], mret);
+  }
+}
+
+__global__ void clear_step_counters(const cmbpo_rollout_t r) {
+  r.iscal[CMBPO_I_N_STORED] = 0;
+}
+
+// ---- compact: ordered alive list from the alive mask ---------------------------------------------
+__global__ __launch_bounds__(kScanThreads) void compact_kernel(const cmbpo_rollout_t r) {
+  __shared__ int sm_i[17];
+  const int tid = threadIdx.x;
+  const int n = r.iscal[CMBPO_I_N_ALIVE];
+  int carry = 0;
+  for (int base = 0; base < n; base += kScanThreads) {
+    const int i = base + tid;
+    int b = -1, flag = 0;
+    if (i < n) {
+      b = r.alive_idx[i];
+      flag = r.alive[b] ? 1 : 0;
+    }
+    int total;
+    const int excl = block_excl_scan(flag, sm_i, &total);
+    if (flag) r.alive_idx_out[carry + excl] = b;
+    carry += total;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    r.iscal[CMBPO_I_N_ALIVE_OUT] = carry;
+    r.iscal[CMBPO_I_N_ALIVE] = carry;  // the caller swaps alive_idx <-> alive_idx_out
+  }
+}
+
+// ---- get(): offsets, moments, flatten ------------------------------------------------------------
+__global__ __launch_bounds__(kScanThreads) void offsets_kernel(const cmbpo_rollout_t r, int32_t *offs) {
+  __shared__ int sm_i[17];
+  const int tid = threadIdx.x;
+  int carry = 0;
+  for (int base = 0; base < r.B; base += kScanThreads) {
+    const int b = base + tid;
+    const int v = (b < r.B) ? r.len[b] : 0;
+    int total;
+    const int excl = block_excl_scan(v, sm_i, &total);
+    if (b < r.B) offs[b] = carry + excl;
+    carry += total;
+  }
+  if (tid == 0) offs[r.B] = carry;
+}
+
+// stats layout: [0] n  [1] adv_mean  [2] adv_std  [3] cadv_mean  [4] ret_mean  [5] cret_mean
+//               [8] n (raw)  [9] sum adv  [10] sum cadv  [11] sum ret  [12] sum cret  [13] sum (adv-mean)^2
+__global__ __launch_bounds__(256) void moments_kernel(const cmbpo_rollout_t r, int pass, double *st) {
+  __shared__ double sm_d[16];
+  const size_t B = (size_t)r.B;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+  const float mean = (float)st[1];
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < r.B; b += gridDim.x * blockDim.x) {
+    const int L = r.len[b];
+    for (int t = 0; t < L; ++t) {
+      const size_t o = (size_t)t * B + b;
+      if (pass == 0) {
+        s0 += 1.0; s1 += r.adv_buf[o]; s2 += r.cadv_buf[o]; s3 += r.ret_buf[o]; s4 += r.cret_buf[o];
+      } else {
+        const float d = __fsub_rn(r.adv_buf[o], mean);  // (x - mean)**2 in float32 (mpi_tools.py:86)
+        s0 += (double)__fmul_rn(d, d);
+      }
+    }
+  }
+  if (pass == 0) {
+    const double a0 = block_sum(s0, sm_d), a1 = block_sum(s1, sm_d), a2 = block_sum(s2, sm_d);
+    const double a3 = block_sum(s3, sm_d), a4 = block_sum(s4, sm_d);
+    if (threadIdx.x == 0) {
+      atomicAdd(&st[8], a0); atomicAdd(&st[9], a1); atomicAdd(&st[10], a2);
+      atomicAdd(&st[11], a3); atomicAdd(&st[12], a4);
+    }
+  } else {
+    const double a0 = block_sum(s0, sm_d);
+    if (threadIdx.x == 0) atomicAdd(&st[13], a0);
+  }
+}
+
+__global__ void moments_finalize(int pass, double *st) {
+  if (pass == 1) {
+    const double n = st[8];
+    st[0] = n;
+    st[1] = n > 0 ? st[9] / n : 0.0;
+    st[3] = n > 0 ? st[10] / n : 0.0;
+    st[4] = n > 0 ? st[11] / n : 0.0;
+    st[5] = n > 0 ? st[12] / n : 0.0;
+  } else {
+    const double n = st[8];
+    st[2] = n > 0 ? sqrt(st[13] / n) : 0.0;
+  }
+}
+
+constexpr int kFlatRows = 64;
+
+struct FlatArgs {
+  float *out[12];
+};
+
+__global__ __launch_bounds__(256) void flatten_kernel(const cmbpo_rollout_t r, const int32_t *offs,
+                                                      const double *st, const FlatArgs fa) {
+  extern __shared__ unsigned short tb[];  // [<= kFlatRows * T]  (b_local << 8) | t
+  const int b0 = blockIdx.x * kFlatRows;
+  const int b1 = min(r.B, b0 + kFlatRows);
+  const int o0 = offs[b0], cnt = offs[b1] - o0;
+  if (cnt == 0) return;
+  for (int e = threadIdx.x; e < (b1 - b0) * r.T; e += blockDim.x) {
+    const int bl = e / r.T, t = e - bl * r.T;
+    const int b = b0 + bl;
+    if (t < r.len[b]) tb[offs[b] - o0 + t] = (unsigned short)((bl << 8) | t);
+  }
+  __syncthreads();
+  const size_t B = (size_t)r.B;
+  const int D = r.obs_dim, A = r.act_dim;
+  const float adv_mean = (float)st[1], adv_den = (float)st[2] + 1e-8f, cadv_mean = (float)st[3];
+  // vector fields: obs (0), act (1), log_std (10), mu (11)
+  const float *vsrc[4] = {r.obs_buf, r.act_buf, r.ls_buf, r.mu_buf};
+  const int vdst[4] = {0, 1, 10, 11};
+  const int vdim[4] = {D, A, A, A};
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int dim = vdim[f];
+    float *dst = fa.out[vdst[f]] + (size_t)o0 * dim;
+    for (int e = threadIdx.x; e < cnt * dim; e += blockDim.x) {
+      const int p = e / dim, d = e - p * dim;
+      const int code = tb[p];
+      const size_t src = ((size_t)(code & 255) * B + (b0 + (code >> 8))) * dim + d;
+      dst[e] = vsrc[f][src];
+    }
+  }
+  // scalar fields: adv 2, cadv 3, ret 4, cret 5, logp 6, val 7, cval 8, cost 9
+  for (int p = threadIdx.x; p < cnt; p += blockDim.x) {
+    const int code = tb[p];
+    const size_t src = (size_t)(code & 255) * B + (b0 + (code >> 8));
+    const size_t o = (size_t)o0 + p;
+    fa.out[2][o] = __fsub_rn(r.adv_buf[src], adv_mean) / adv_den;   // modelbuffer.py:199
+    fa.out[3][o] = __fsub_rn(r.cadv_buf[src], cadv_mean);           // modelbuffer.py:204
+    fa.out[4][o] = r.ret_buf[src];
+    fa.out[5][o] = r.cret_buf[src];
+    fa.out[6][o] = r.logp_buf[src];
+    fa.out[7][o] = r.val_buf[src];
+    fa.out[8][o] = r.cval_buf[src];
+    fa.out[9][o] = r.cost_buf[src];
+  }
+}
+
+int check_rollout(const cmbpo_rollout_t *r, const char *who) {
+  CMBPO_REQUIRE(r != nullptr, "%s: rollout struct is NULL", who);
+  CMBPO_REQUIRE(r->B >= 1 && r->T >= 1 && r->T <= 255 && r->obs_dim >= 1 && r->act_dim >= 1,
+                "%s: bad sizes B=%d T=%d obs=%d act=%d", who, r->B, r->T, r->obs_dim, r->act_dim);
+  CMBPO_REQUIRE(r->alive_idx && r->alive_idx_out && r->iscal && r->dscal && r->alive && r->fin_code && r->len,
+                "%s: NULL state array", who);
+  CMBPO_REQUIRE(r->ptr >= 0 && r->ptr <= r->T, "%s: ptr %d outside [0, T=%d]", who, r->ptr, r->T);
+  return CMBPO_OK;
+}
+
+}  // namespace
+
+extern "C" int cmbpo_rollout_reset(const cmbpo_rollout_t *r, void *stream) {
+  if (int rc = check_rollout(r, "cmbpo_rollout_reset")) return rc;
+  CMBPO_REQUIRE(r->dkl_acc && r->path_ret && r->path_cost && r->path_dyn_var, "cmbpo_rollout_reset: NULL accumulators");
+  const int n = r->B > 32 ? r->B : 32;
+  hipLaunchKernelGGL(reset_kernel, dim3(cmbpo_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, *r);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_rollout_decide(const cmbpo_rollout_t *r, void *stream) {
+  if (int rc = check_rollout(r, "cmbpo_rollout_decide")) return rc;
+  CMBPO_REQUIRE(r->dkl_t && r->dkl_acc, "cmbpo_rollout_decide: NULL dkl arrays");
+  CMBPO_REQUIRE(r->world >= 1 && r->rank >= 0 && r->rank < r->world, "cmbpo_rollout_decide: bad rank/world");
+  hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r, 0);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_rollout_count(const cmbpo_rollout_t *r, void *stream) {
+  if (int rc = check_rollout(r, "cmbpo_rollout_count")) return rc;
+  CMBPO_REQUIRE(r->dkl_t && r->dkl_acc, "cmbpo_rollout_count: NULL dkl arrays");
+  hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r, 1);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_rollout_finish(const cmbpo_rollout_t *r, int mode, void *stream) {
+  if (int rc = check_rollout(r, "cmbpo_rollout_finish")) return rc;
+  CMBPO_REQUIRE(mode >= 0 && mode <= 2, "cmbpo_rollout_finish: bad mode %d", mode);
+  CMBPO_REQUIRE(r->rew_buf && r->val_buf && r->cost_buf && r->cval_buf && r->adv_buf && r->ret_buf &&
+                    r->cadv_buf && r->cret_buf,
+                "cmbpo_rollout_finish: NULL buffer");
+  if (mode == 1) CMBPO_REQUIRE(r->v_n && r->vc_n && r->term_t, "cmbpo_rollout_finish: POST needs v_n, vc_n, term_t");
+  else CMBPO_REQUIRE(r->v_t && r->vc_t, "cmbpo_rollout_finish: needs v_t, vc_t");
+  hipLaunchKernelGGL(finish_kernel, dim3(cmbpo_ceil_div(r->B, 256)), dim3(256), 0, (hipStream_t)stream, *r, mode);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_rollout_store(const cmbpo_rollout_t *r, void *stream) {
+  if (int rc = check_rollout(r, "cmbpo_rollout_store")) return rc;
+  CMBPO_REQUIRE(r->ptr < r->T, "cmbpo_rollout_store: buffer full (ptr %d == T)", r->ptr);  // modelbuffer.py:115
+  CMBPO_REQUIRE(r->cur_obs && r->act_t && r->logp_t && r->mu_t && r->ls_t && r->v_t && r->vc_t && r->rew_t &&
+                    r->cost_t && r->dkl_t && r->epv_t,
+                "cmbpo_rollout_store: NULL step array");
+  CMBPO_REQUIRE(r->obs_buf && r->act_buf && r->mu_buf && r->ls_buf && r->rew_buf && r->val_buf && r->cost_buf &&
+                    r->cval_buf && r->logp_buf,
+                "cmbpo_rollout_store: NULL buffer");
+  hipLaunchKernelGGL(clear_step_counters, dim3(1), dim3(1), 0, (hipStream_t)stream, *r);
+  hipLaunchKernelGGL(store_kernel, dim3(cmbpo_ceil_div(r->B, kStoreRows)), dim3(256), 0, (hipStream_t)stream, *r);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_rollout_compact(const cmbpo_rollout_t *r, void *stream) {
+  if (int rc = check_rollout(r, "cmbpo_rollout_compact")) return rc;
+  hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_buffer_offsets(const cmbpo_rollout_t *r, int32_t *d_offsets, void *stream) {
+  if (int rc = check_rollout(r, "cmbpo_buffer_offsets")) return rc;
+  CMBPO_REQUIRE(d_offsets != nullptr, "cmbpo_buffer_offsets: NULL offsets");
+  hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r, d_offsets);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_buffer_moments(const cmbpo_rollout_t *r, int pass, double *d_stats, void *stream) {
+  if (int rc = check_rollout(r, "cmbpo_buffer_moments")) return rc;
+  CMBPO_REQUIRE(pass >= 0 && pass <= 3 && d_stats, "cmbpo_buffer_moments: bad pass %d / NULL stats", pass);
+  hipStream_t s = (hipStream_t)stream;
+  if (pass == 0) CMBPO_HIP_CHECK(hipMemsetAsync(d_stats, 0, 16 * sizeof(double), s));
+  if (pass == 0 || pass == 2) {
+    const int blocks = cmbpo_ceil_div(r->B, 256) < 1024 ? cmbpo_ceil_div(r->B, 256) : 1024;
+    hipLaunchKernelGGL(moments_kernel, dim3(blocks), dim3(256), 0, s, *r, pass == 0 ? 0 : 1, d_stats);
+  } else {
+    hipLaunchKernelGGL(moments_finalize, dim3(1), dim3(1), 0, s, pass, d_stats);
+  }
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_buffer_flatten(const cmbpo_rollout_t *r, const int32_t *d_offsets, const double *d_stats,
+                                    float *const *h_out12, void *stream) {
+  if (int rc = check_rollout(r, "cmbpo_buffer_flatten")) return rc;
+  CMBPO_REQUIRE(d_offsets && d_stats && h_out12, "cmbpo_buffer_flatten: NULL argument");
+  FlatArgs fa;
+  for (int k = 0; k < 12; ++k) {
+    CMBPO_REQUIRE(h_out12[k] != nullptr, "cmbpo_buffer_flatten: output %d is NULL", k);
+    fa.out[k] = h_out12[k];
+  }
+  const size_t lds = (size_t)kFlatRows * r->T * sizeof(unsigned short);
+  hipLaunchKernelGGL(flatten_kernel, dim3(cmbpo_ceil_div(r->B, kFlatRows)), dim3(256), lds, (hipStream_t)stream,
+                     *r, d_offsets, d_stats, fa);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}

@@ -1,0 +1,253 @@
+"""ModelSampler -- host-side mirror of ``samplers/model_sampler.py:13-444`` over device-resident state.
+
+Same constructor / ``initialize(env, policy, pool)`` / ``reset(observations)`` / ``sample(max_samples)``
+/ ``finish_all_paths()`` / ``compute_dynamics_dkl`` / ``set_rollout_dkl`` / ``set_max_path_length`` and the
+``dyn_dkl`` / ``_total_samples`` attributes the trainer reads (``algorithms/cmbpo.py:197-201,251-266``).
+
+One ``sample()`` = one imagined step of every alive branch, entirely on the GPU:
+
+    policy forward (HIP)  ->  ensemble forward + FakeEnv post (HIP)  ->  decide  ->  finish(PRE)
+    ->  store  ->  critics on next_obs (HIP)  ->  finish(POST)  ->  compact
+
+Event order, bootstraps and the budget rule follow ``model_sampler.py:239-375`` (see the kernels in
+``csrc/rollout_state.hip``).  Two restructurings that do not change results:
+  * V / VC of the *next* observation are evaluated once after the store: they bootstrap the horizon /
+    terminal finishes of this step (``:350-367``) and ARE the ``v_t`` / ``vc_t`` of the next step (the critics
+    are deterministic), so the extra ``get_v`` / ``get_vc`` calls of ``_finish_paths`` (``:401-407``) vanish;
+  * branches never move: an ordered alive list replaces the boolean-mask compaction (``:300-311``).
+
+``sample()`` returns ``(next_obs, reward, terminal, info)`` like the reference, but as slot-indexed CUDA
+tensors (the trainer only reads ``info['alive_ratio']``, ``algorithms/cmbpo.py:254-263``).
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+
+EPS = 1e-8  # utilities/utils.py:19
+
+
+class ModelSampler:
+    def __init__(self, max_path_length, batch_size=1000, rollout_mode=False, logger=None, seed=0,
+                 comm=None):
+        self._max_path_length = int(max_path_length)
+        self.batch_size = int(batch_size)
+        self.rollout_mode = rollout_mode
+        self.logger = logger
+        self.comm = comm
+        self.dkl_lim = float("inf")
+        self.env = self.policy = self.pool = None
+        self._n_episodes = 0
+        self._seed = int(seed)
+        self._gen = None
+        self._host = dict(total_samples=0.0, total_dkl=0.0)
+        self._calib_total_dkl = 0.0
+        self._calib_total_samples = 0.0
+        self._diag = None
+
+    # -- wiring -----------------------------------------------------------------------------------
+    def initialize(self, env, policy, pool):
+        self.env, self.policy, self.pool = env, policy, pool
+        self.device = pool.device
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(self._seed)
+        self._elites = None
+
+    def set_policy(self, policy):
+        self.policy = policy
+
+    def set_logger(self, logger):
+        self.logger = logger
+
+    def terminate(self):
+        self.env.close()
+
+    def set_rollout_dkl(self, dkl):
+        self.dkl_lim = float(dkl)
+
+    def set_max_path_length(self, path_length):
+        self._max_path_length = int(path_length)
+
+    def batch_ready(self):
+        return self.pool.size >= self.pool.max_size
+
+    # -- accumulators ---------------------------------------------------------------------------------
+    def _read_scalars(self):
+        isc = self.pool.sync_counters()
+        dsc = self.pool.t["dscal"].cpu().numpy()
+        self._dsc = dsc
+        return isc, dsc
+
+    @property
+    def _total_samples(self):
+        return self._host["total_samples"]
+
+    @property
+    def _total_dkl(self):
+        return self._host["total_dkl"]
+
+    @property
+    def dyn_dkl(self):
+        """model_sampler.py:175-177."""
+        return self._host["total_dkl"] / (self._host["total_samples"] + EPS)
+
+    def get_diagnostics(self):
+        """model_sampler.py:89-133 (same keys; variance terms the reference never fills stay 0)."""
+        _, d = self._read_scalars()
+        L = _lib
+        tot = d[L.D_TOTAL_SAMPLES]
+        diagnostics = OrderedDict({"pool-size": self.pool.size})
+        diagnostics.update({
+            "msampler/samples_added": tot,
+            "msampler/rollout_H_max": self._n_episodes,
+            "msampler/rollout_H_mean": tot / (self.batch_size + EPS),
+            "msampler/rew_var_perstep": 0.0,
+            "msampler/cost_var_perstep": 0.0,
+            "msampler/dyn_var_perstep": d[L.D_TOTAL_DYN_EP_VAR] / (tot + EPS),
+            "msampler/cost_rate": d[L.D_SUM_PATH_COST] / (tot + EPS),
+            "msampler/rew_rate": d[L.D_SUM_PATH_RET] / (tot + EPS),
+            "msampler/v_mean": d[L.D_TOTAL_VS] / (tot + EPS),
+            "msampler/cv_mean": d[L.D_TOTAL_CVS] / (tot + EPS),
+            "msampler/ens_DKL": d[L.D_TOTAL_DKL] / (tot + EPS),
+            "msampler/ens_mean_var": 0.0,
+            "msampler/max_path_return": d[L.D_MAX_PATH_RETURN],
+            "msampler/max_dkl": d[L.D_MAX_DKL],
+        })
+        return diagnostics
+
+    # -- rollout -------------------------------------------------------------------------------------
+    def _critics(self, obs_key, v_key, vc_key, n):
+        t = self.pool.t
+        idx = t["alive_idx"]
+        lib, stream = _lib.lib(), _lib.current_stream()
+        for net, key in ((self.policy.v, v_key), (self.policy.vc, vc_key)):
+            _lib.check(lib.cmbpo_ens_predict_mean(net.mlp.handle, t[obs_key].data_ptr(), self.pool.obs_dim,
+                                                  idx.data_ptr(), None, n, t[key].data_ptr(), stream),
+                       "cmbpo_ens_predict_mean")
+
+    def reset(self, observations):
+        """model_sampler.py:203-237: start all branches from `observations` [B, obs]."""
+        self.batch_size = int(observations.shape[0])
+        self.policy.reset()
+        pool = self.pool
+        with torch.cuda.device(self.device):
+            pool.reset(self.batch_size)
+            obs = observations if isinstance(observations, torch.Tensor) else \
+                torch.from_numpy(np.ascontiguousarray(observations, dtype=np.float32))
+            pool.t["cur_obs"].copy_(obs.to(self.device, torch.float32))
+            pool.rs.max_path_length = self._max_path_length
+            pool.rs.uncertainty_mode = 1 if self.rollout_mode == "uncertainty" else 0
+            pool.rs.dkl_lim = float(self.dkl_lim)
+            if self.comm is not None:
+                pool.rs.rank, pool.rs.world = self.comm.rank, self.comm.world
+            # critics at the start states: v_t / vc_t of the first step
+            self._critics("cur_obs", "v_t", "vc_t", self.batch_size)
+        self._n_episodes = 0
+        self._host = dict(total_samples=0.0, total_dkl=0.0)
+        elites = np.asarray(self.env._model.elite_inds, dtype=np.int32)
+        self._elites = torch.as_tensor(elites, device=self.device)
+
+    def _scatter(self, compact, idx, width=None, dtype=torch.float32):
+        """Test hook: a draw given in the reference's compact (alive-only) order -> slot order."""
+        B = self.batch_size
+        shape = (B,) if width is None else (B, width)
+        full = torch.zeros(shape, dtype=dtype, device=self.device)
+        full[idx.long()] = torch.as_tensor(np.ascontiguousarray(compact), device=self.device).to(dtype)
+        return full
+
+    def sample(self, max_samples=None, eps=None, model_inds=None):
+        """One imagined step of every alive branch (model_sampler.py:239-375).
+
+        eps / model_inds (optional, compact alive-only order like the reference's arrays) inject the
+        N(0,1) action noise (ac_network.py:109) and the per-branch elite draw (fake_env.py:174-178).
+        """
+        pool, env, pol = self.pool, self.env, self.policy
+        assert pool.has_room                       # pool full! empty before sampling.
+        assert pool.n_alive > 0                    # reset before sampling !
+        self._n_episodes += 1
+        t, rs = pool.t, pool.rs
+        n, B, A = pool.n_alive, self.batch_size, pool.act_dim
+        with torch.cuda.device(self.device):
+            idx = t["alive_idx"]
+            if eps is None:
+                eps_t = torch.randn((B, A), generator=self._gen, dtype=torch.float32, device=self.device)
+            else:
+                eps_t = self._scatter(eps, idx[:n], A)
+            if model_inds is None:
+                draw = torch.randint(0, len(self._elites), (B,), generator=self._gen, device=self.device)
+                inds_t = self._elites[draw]
+            else:
+                inds_t = self._scatter(model_inds, idx[:n], None, torch.int32)
+            # policy: pi, logp, mu, log_std at the current observations
+            pol.actor.forward_device(t["cur_obs"], eps_t,
+                                     dict(pi=t["act_t"], logp_pi=t["logp_t"], mu=t["mu_t"], log_std=t["ls_t"]),
+                                     row_idx=idx, n_rows=n)
+            # dynamics ensemble + FakeEnv post-processing
+            if getattr(self, "_scratch", None) is None or self._scratch[0].shape[1] != B:
+                E, O = env._model.num_nets, env.output_dim
+                self._scratch = (torch.empty((E, B, O), dtype=torch.float32, device=self.device),
+                                 torch.empty((E, B, O), dtype=torch.float32, device=self.device))
+            env.step_device(t["cur_obs"], t["act_t"], inds_t,
+                            dict(next_obs=t["next_obs"], rew=t["rew_t"], term=t["term_t"], cost=t["cost_t"],
+                                 dkl_path=t["dkl_t"], ep_var_mean=t["epv_t"]),
+                            row_idx=idx, n_rows=n, scratch=self._scratch)
+            rs.max_samples = int(max_samples) if max_samples else 0
+            rs.dkl_lim = float(self.dkl_lim)
+            rs.max_path_length = self._max_path_length
+            if self.comm is not None and self.comm.world > 1 and rs.max_samples > 0:
+                pool._call("cmbpo_rollout_count")
+                self._g_counts = self.comm.all_gather_i32(t["iscal"][8:12])
+                rs.g_counts = self._g_counts.data_ptr()
+            pool._call("cmbpo_rollout_decide")
+            pool._call("cmbpo_rollout_finish", 0)
+            pool._call("cmbpo_rollout_store")
+            self._critics("next_obs", "v_n", "vc_n", n)
+            pool._call("cmbpo_rollout_finish", 1)
+            pool._call("cmbpo_rollout_compact")
+            pool.swap("alive_idx", "alive_idx_out")
+            pool.swap("cur_obs", "next_obs")
+            pool.swap("v_t", "v_n")
+            pool.swap("vc_t", "vc_n")
+            pool.ptr += 1
+            rs.ptr = pool.ptr
+            isc, dsc = self._read_scalars()
+        self._host["total_samples"] = float(dsc[_lib.D_TOTAL_SAMPLES])
+        self._host["total_dkl"] = float(dsc[_lib.D_TOTAL_DKL])
+        alive = pool.n_alive
+        if self.comm is not None and self.comm.world > 1:
+            g = self.comm.all_reduce_host([alive, self.batch_size, self._host["total_samples"]])
+            alive_ratio, self._global_total_samples = g[0] / g[1], g[2]
+        else:
+            alive_ratio = alive / self.batch_size
+        info = {"alive_ratio": alive_ratio, "ensemble_dkl_path": t["dkl_t"], "cost": t["cost_t"]}
+        # after the swap the step's next_obs is the new cur_obs
+        return t["cur_obs"], t["rew_t"], t["term_t"], info
+
+    def finish_all_paths(self):
+        """model_sampler.py:418-444: bootstrap-finish whatever is still alive, return diagnostics."""
+        if self.pool.n_alive > 0:
+            with torch.cuda.device(self.device):
+                self.pool._call("cmbpo_rollout_finish", 2)
+                self.pool._call("cmbpo_rollout_compact")
+                self.pool.swap("alive_idx", "alive_idx_out")
+            self.pool.sync_counters()
+            assert self.pool.n_alive == 0   # something went wrong with finishing all paths
+        return self.get_diagnostics()
+
+    def compute_dynamics_dkl(self, obs_batch, depth=1):
+        """model_sampler.py:151-167: mean per-step ensemble DKL along `depth` policy steps (calibration)."""
+        obs = obs_batch if isinstance(obs_batch, torch.Tensor) else \
+            torch.from_numpy(np.ascontiguousarray(obs_batch, dtype=np.float32))
+        obs = obs.to(self.device, torch.float32)
+        for _ in range(depth):
+            n = obs.shape[0]
+            if n == 0:
+                break
+            outs = self.policy.get_action_outs(obs)
+            next_obs, _, terminal, info = self.env.step(obs, outs["pi"])
+            self._host["total_dkl"] += float(info["ensemble_dkl_mean"]) * n
+            self._host["total_samples"] += n
+            obs = next_obs[~terminal[:, 0]]
+        return self.dyn_dkl * depth

@@ -131,6 +131,116 @@ int cmbpo_fakeenv_post(int task, int ensemble, int obs_dim, int act_dim,
                        float *d_dkl_path, float *d_ep_var_mean,
                        float *d_ep_var, void *stream);
 
+/* ------------------------------------------------------------------------ *
+ * Device-resident rollout state: the fused counterpart of ModelSampler
+ * (samplers/model_sampler.py:203-444) + ModelBuffer (buffers/modelbuffer.py).
+ * Every array is owned by the caller; branch slots never move (mask-in-place
+ * + an ordered alive list instead of the reference's per-step compaction,
+ * samplers/model_sampler.py:300-311).  Buffers are TIME-MAJOR [T][B][...]
+ * so that per-step stores and the per-branch GAE scan are both coalesced; the
+ * reference's (B, T) order is restored by cmbpo_buffer_flatten (get()).
+ * ------------------------------------------------------------------------ */
+typedef struct cmbpo_rollout {
+  int32_t B, T, obs_dim, act_dim;
+  int32_t max_path_length;  /* sampler horizon (model_sampler.py:352)          */
+  int32_t ptr;              /* column of the next store (modelbuffer.py:135)   */
+  int32_t uncertainty_mode; /* rollout_mode == 'uncertainty' (:275-279)        */
+  int32_t rank, world;      /* shard id / count (budget rule offsets)          */
+  int64_t max_samples;      /* budget of sample(max_samples); <= 0: none       */
+  double dkl_lim;           /* set_rollout_dkl (:169-170)                      */
+  double gamma, lam, cost_gamma, cost_lam; /* modelbuffer.py:41-51             */
+  /* ordered alive list (ascending slot ids) and scalars */
+  int32_t *alive_idx;       /* [B] current list                                */
+  int32_t *alive_idx_out;   /* [B] list written by cmbpo_rollout_compact       */
+  int32_t *iscal;           /* [32] see CMBPO_I_*                              */
+  double *dscal;            /* [32] see CMBPO_D_*                              */
+  const int32_t *g_counts;  /* [world][4] gathered {n_alive,n_unc,..} or NULL  */
+  uint8_t *alive;           /* [B] !terminated_paths_mask                      */
+  uint8_t *fin_code;        /* [B] 0 keep, 1 finish w/ bootstrap, 2 terminal   */
+  int32_t *len;             /* [B] populated entries of the branch             */
+  /* per-step values, slot indexed */
+  const float *cur_obs;     /* [B,obs]  observation the step starts from       */
+  const float *next_obs;    /* [B,obs]                                         */
+  const float *act_t, *logp_t, *mu_t, *ls_t; /* [B,act] / [B]                  */
+  const float *v_t, *vc_t;  /* [B] critics at cur_obs                          */
+  const float *v_n, *vc_n;  /* [B] critics at next_obs                         */
+  const float *rew_t, *cost_t, *dkl_t, *epv_t; /* [B]                          */
+  const uint8_t *term_t;    /* [B]                                             */
+  double *dkl_acc, *path_ret, *path_cost, *path_dyn_var; /* [B] (float64 in the reference) */
+  /* time-major buffers */
+  float *obs_buf, *act_buf, *mu_buf, *ls_buf;             /* [T,B,dim]         */
+  float *rew_buf, *val_buf, *cost_buf, *cval_buf, *logp_buf; /* [T,B]          */
+  float *adv_buf, *ret_buf, *cadv_buf, *cret_buf;         /* [T,B]             */
+} cmbpo_rollout_t;
+
+/* iscal slots */
+#define CMBPO_I_N_ALIVE 0   /* length of alive_idx                              */
+#define CMBPO_I_N_UNC 1     /* too-uncertain rows of this step (local)          */
+#define CMBPO_I_N_FIN_PRE 2 /* rows finished before the store                   */
+#define CMBPO_I_N_STORED 3  /* rows stored this step                            */
+#define CMBPO_I_N_ALIVE_OUT 4 /* length of alive_idx_out after compact          */
+#define CMBPO_I_SIZE 5      /* populated entries in the buffer (pool.size)      */
+/* dscal slots (sampler accumulators, model_sampler.py:314-333) */
+#define CMBPO_D_TOTAL_SAMPLES 0
+#define CMBPO_D_TOTAL_COST 1
+#define CMBPO_D_TOTAL_REW 2
+#define CMBPO_D_TOTAL_VS 3
+#define CMBPO_D_TOTAL_CVS 4
+#define CMBPO_D_TOTAL_DKL 5
+#define CMBPO_D_TOTAL_DYN_EP_VAR 6
+#define CMBPO_D_MAX_DKL 7
+#define CMBPO_D_MAX_PATH_RETURN 8
+#define CMBPO_D_DKL_SUM_T 9     /* sum of dkl_t over the rows stepped this call */
+#define CMBPO_D_STEP_MAX_DKL 10
+#define CMBPO_D_SUM_PATH_RET 11
+#define CMBPO_D_SUM_PATH_COST 12
+
+/* ModelSampler.reset + ModelBuffer.reset (model_sampler.py:203-237,
+ * modelbuffer.py:53-98): all B branches alive, lists / accumulators zeroed.
+ * Does not touch the big buffers (no realloc, no memset: entries are only
+ * read below `len`). */
+int cmbpo_rollout_reset(const cmbpo_rollout_t *r, void *stream);
+
+/* Uncertainty test on accumulated + new DKL BEFORE storing and the budget
+ * early-termination of the first n surviving rows by index
+ * (model_sampler.py:275-287) -> fin_code, counters. */
+int cmbpo_rollout_decide(const cmbpo_rollout_t *r, void *stream);
+/* Counting half of the above only: writes iscal[8..11] = {n_alive, n_unc,
+ * total_samples, 0}, the row a sharded run all-gathers into g_counts before
+ * cmbpo_rollout_decide (budget rule across shards). */
+int cmbpo_rollout_count(const cmbpo_rollout_t *r, void *stream);
+
+/* ModelBuffer.finish_path_multiple (modelbuffer.py:138-182) = reward + cost GAE
+ * (utilities/utils.py:184-188 discount_cumsum, float64 recurrence) for the rows
+ * selected by `mode`, then marks them terminated:
+ *   0 PRE : rows with fin_code != 0, bootstrap V/VC of the pre-step obs (:290,401-407)
+ *   1 POST: stored rows; horizon (path_length >= max_path_length-1, :350-353) finishes
+ *           all with V/VC(next_obs); else env-terminal rows with last_val = 0 but
+ *           last_cval = VC(next_obs) (:357-367)
+ *   2 ALL : finish_all_paths (:418-444), bootstrap V/VC of the current obs. */
+int cmbpo_rollout_finish(const cmbpo_rollout_t *r, int mode, void *stream);
+
+/* ModelBuffer.store_multiple for the surviving rows at column ptr + the sampler
+ * accumulators (modelbuffer.py:114-135, model_sampler.py:314-346). */
+int cmbpo_rollout_store(const cmbpo_rollout_t *r, void *stream);
+
+/* Rebuild the ordered alive list from `alive` (replaces the boolean-mask
+ * compaction of model_sampler.py:300-311,361-372). */
+int cmbpo_rollout_compact(const cmbpo_rollout_t *r, void *stream);
+
+/* ModelBuffer.get (modelbuffer.py:184-226): d_offsets[B+1] = exclusive scan of
+ * len; d_stats[8] = {n, adv_mean, adv_std, cadv_mean, ret_mean, cret_mean}
+ * (two-pass mean / std of utilities/mpi_tools.py:71-92).  With d_gstats
+ * (global statistics after an all-reduce) NULL the local ones are used. */
+int cmbpo_buffer_offsets(const cmbpo_rollout_t *r, int32_t *d_offsets, void *stream);
+int cmbpo_buffer_moments(const cmbpo_rollout_t *r, int pass, double *d_stats, void *stream);
+/* Flatten in branch-major, time-minor order into the 12-array list
+ * [obs, act, adv, cadv, ret, cret, logp, val, cval, cost, log_std, mu]
+ * (modelbuffer.py:212-218), normalising adv by (mean, std + 1e-8) and centring
+ * cadv (:198-204).  d_out[12] are device pointers sized for offsets[B] rows. */
+int cmbpo_buffer_flatten(const cmbpo_rollout_t *r, const int32_t *d_offsets,
+                         const double *d_stats, float *const *h_out12, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

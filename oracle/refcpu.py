@@ -227,3 +227,215 @@ def fake_env_step(obs, act, pred_mean, pred_var, model_inds, task):
     info = dict(ensemble_dkl_mean=dkl_mean, ensemble_dkl_path=dkl_path, ensemble_ep_var=ep_var,
                 rew=r, cost=c)
     return next_obs, r, terms, info
+
+
+# ----------------------------------------------------------------------------------------
+# GAE / statistics / CG (NumPy half)
+# ----------------------------------------------------------------------------------------
+def discount_cumsum(x, discount, lam):
+    """utilities/utils.py:184-188, un-weighted branch, last axis.
+
+    scipy.signal.lfilter([1], [1, -discount*lam]) on the reversed rows: a float64 first-order
+    recurrence y_t = x_t + (discount*lam) * y_{t+1}, product and sum rounded separately.
+    Input keeps its dtype for the deltas; output is float64 (lfilter promotes float32 input).
+    """
+    x = np.asarray(x)
+    if x.size == 0:
+        return np.array(x)
+    c = float(discount * lam)
+    y = np.zeros(x.shape, dtype=np.float64)
+    acc = np.zeros(x.shape[:-1], dtype=np.float64)
+    for t in range(x.shape[-1] - 1, -1, -1):
+        acc = x[..., t].astype(np.float64) + c * acc
+        y[..., t] = acc
+    return y
+
+
+def mpi_statistics_scalar(x):
+    """utilities/mpi_tools.py:71-87 at world size 1: float32 two-pass mean / std."""
+    x = np.array(x, dtype=F32)
+    s = np.asarray([np.sum(x), len(x)], dtype=F32)
+    mean = s[0] / s[1]
+    sq = np.asarray(np.sum((x - mean) ** 2), dtype=F32)
+    return mean, np.sqrt(sq / s[1])
+
+
+def cg(Ax, b, cg_iters=10):
+    """utilities/trust_region.py:32-45: plain CG from x = 0, fixed iteration count, EPS in alpha."""
+    x = np.zeros_like(b)
+    r = b.copy()
+    p = r.copy()
+    rr = np.dot(r, r)
+    for _ in range(cg_iters):
+        z = Ax(p)
+        alpha = rr / (np.dot(p, z) + 1e-8)
+        x += alpha * p
+        r -= alpha * z
+        rr_new = np.dot(r, r)
+        p = r + (rr_new / rr) * p
+        rr = rr_new
+    return x
+
+
+def gae_rows(rew, val, last_val, gamma, lam):
+    """buffers/modelbuffer.py:163-170 for rows [n, L]: returns (adv float32, ret float32).
+
+    dtype follows NumPy promotion in the reference: float32 rows with a float32 bootstrap stay
+    float32 for the deltas; a float64 bootstrap (np.zeros, model_sampler.py:404) promotes them.
+    """
+    last_val = np.asarray(last_val)
+    rews = np.append(rew, last_val[..., None], axis=-1)
+    vals = np.append(val, last_val[..., None], axis=-1)
+    deltas = rews[..., :-1] + gamma * vals[..., 1:] - vals[..., :-1]
+    adv = discount_cumsum(deltas, gamma, lam).astype(F32)
+    return adv, (adv + val).astype(F32)
+
+
+# ----------------------------------------------------------------------------------------
+# ModelSampler + ModelBuffer, restated on fixed branch slots (NumPy half)
+# ----------------------------------------------------------------------------------------
+class RolloutOracle:
+    """samplers/model_sampler.py:203-444 + buffers/modelbuffer.py:53-226, without array compaction.
+
+    model(x)->(mean,var)[E,n,out]; policy(obs, eps)->dict(pi, logp_pi, mu, log_std); v(obs), vc(obs)->[n].
+    Random draws are inputs: eps[step][n_alive, act], inds[step][n_alive] in alive (index) order.
+    """
+
+    def __init__(self, model, policy, v, vc, task, obs_dim, act_dim, max_path_length, mode, dkl_lim,
+                 gamma=0.99, lam=0.95, cost_gamma=0.97, cost_lam=0.5):
+        self.model, self.policy, self.v, self.vc, self.task = model, policy, v, vc, task
+        self.D, self.A, self.T = obs_dim, act_dim, max_path_length
+        self.mode, self.dkl_lim = mode, dkl_lim
+        self.g, self.l, self.cg_, self.cl = gamma, lam, cost_gamma, cost_lam
+
+    def reset(self, start):
+        B, T, D, A = start.shape[0], self.T, self.D, self.A
+        self.B = B
+        self.cur = np.array(start, dtype=F32)
+        self.alive = np.ones(B, dtype=bool)
+        self.len = np.zeros(B, dtype=np.int64)
+        z = lambda *s: np.zeros(s, dtype=F32)
+        self.buf = dict(obs=z(B, T, D), act=z(B, T, A), mu=z(B, T, A), log_std=z(B, T, A), rew=z(B, T),
+                        val=z(B, T), cost=z(B, T), cval=z(B, T), logp=z(B, T), adv=z(B, T), ret=z(B, T),
+                        cadv=z(B, T), cret=z(B, T))
+        self.ptr = 0
+        self.dkl_acc = np.zeros(B)
+        self.path_ret = np.zeros(B)
+        self.path_cost = np.zeros(B)
+        self.tot = dict(samples=0, cost=0.0, rew=0.0, Vs=0.0, CVs=0.0, dkl=0.0, dyn_ep_var=0.0, max_dkl=0.0,
+                        max_path_return=0.0)
+        self.n_episodes = 0
+
+    def _finish(self, slots, last_val, last_cval):
+        """finish_path_multiple (modelbuffer.py:138-182) for the given slots."""
+        if len(slots) == 0:
+            return
+        L = self.ptr
+        if L > 0:
+            b = self.buf
+            adv, ret = gae_rows(b["rew"][slots, :L], b["val"][slots, :L], last_val, self.g, self.l)
+            cadv, cret = gae_rows(b["cost"][slots, :L], b["cval"][slots, :L], last_cval, self.cg_, self.cl)
+            b["adv"][slots, :L], b["ret"][slots, :L] = adv, ret
+            b["cadv"][slots, :L], b["cret"][slots, :L] = cadv, cret
+        self.alive[slots] = False
+
+    def sample(self, eps, inds, max_samples=None):
+        """One step (model_sampler.py:239-375).  Returns alive_ratio."""
+        self.n_episodes += 1
+        idx = np.flatnonzero(self.alive)
+        obs = self.cur[idx]
+        out = self.policy(obs, eps)
+        a, v_t, vc_t = out["pi"], self.v(obs), self.vc(obs)
+        mean, var = self.model(np.concatenate([obs, a], axis=-1))
+        nobs, r, terms, info = fake_env_step(obs, a, mean, var, inds, self.task)
+        r, terms = r[:, 0], terms[:, 0]
+        c = np.squeeze(info["cost"])
+        dkl_path, ep_var = info["ensemble_dkl_path"], info["ensemble_ep_var"]
+        dkl_mean = info["ensemble_dkl_mean"]
+        # uncertainty test on accumulated + new DKL, before storing (:275-279)
+        if self.mode == "uncertainty":
+            unc = self.dkl_acc[idx] + dkl_path >= self.dkl_lim
+        else:
+            unc = np.zeros(len(idx), dtype=bool)
+        # budget: first n surviving rows by index (:282-287)
+        if max_samples:
+            n = self.tot["samples"] + len(idx) - unc.sum()
+            n = max(n - max_samples, 0)
+            surv = np.flatnonzero(~unc)
+            unc = unc.copy()
+            unc[surv[:n]] = True
+        # finish with V/VC bootstrap of the PRE-step obs (:290, :401-407).  The reference calls the
+        # critics again on the subset (BLAS results can differ in the last bit with the batch shape).
+        if unc.any():
+            self._finish(idx[unc], self.v(obs[unc]), self.vc(obs[unc]))
+        keep = ~unc
+        if not keep.any():
+            return 0.0
+        k = idx[keep]
+        self.tot["samples"] += len(k)
+        self.tot["cost"] += c[keep].sum()
+        self.tot["rew"] += r[keep].sum()
+        self.path_ret[k] += r[keep]
+        self.path_cost[k] += c[keep]
+        self.tot["dyn_ep_var"] += ep_var[keep].sum()
+        self.tot["Vs"] += v_t[keep].sum()
+        self.tot["CVs"] += vc_t[keep].sum()
+        self.tot["dkl"] += dkl_mean * len(k)
+        self.tot["max_dkl"] = max(self.tot["max_dkl"], np.max(dkl_path[keep]))
+        self.dkl_acc[k] += dkl_path[keep]
+        self.tot["max_path_return"] = max(self.tot["max_path_return"], np.max(self.path_ret))
+        # store at column ptr (modelbuffer.py:114-135)
+        b, p = self.buf, self.ptr
+        b["obs"][k, p], b["act"][k, p] = obs[keep], a[keep]
+        b["rew"][k, p], b["val"][k, p], b["cost"][k, p], b["cval"][k, p] = r[keep], v_t[keep], c[keep], vc_t[keep]
+        b["logp"][k, p], b["mu"][k, p], b["log_std"][k, p] = out["logp_pi"][keep], out["mu"][keep], out["log_std"][keep]
+        self.len[k] = p + 1
+        self.ptr += 1
+        self.cur[k] = nobs[keep]
+        # horizon (:350-356): everything left finishes with V/VC(next_obs)
+        if self.ptr >= self.T - 1:
+            self._finish(k, self.v(self.cur[k]), self.vc(self.cur[k]))
+            return 0.0
+        # env terminals (:357-367): last_val = float64 zeros, last_cval = VC(next_obs)
+        tk = k[terms[keep]]
+        if len(tk):
+            self._finish(tk, np.zeros(len(tk)), self.vc(self.cur[tk]))
+        if not self.alive.any():
+            return 0.0
+        return self.alive.sum() / self.B
+
+    def finish_all(self):
+        idx = np.flatnonzero(self.alive)
+        if len(idx):
+            self._finish(idx, self.v(self.cur[idx]), self.vc(self.cur[idx]))
+
+    def get(self):
+        """modelbuffer.py:184-226."""
+        assert not self.alive.any()
+        mask = np.arange(self.T)[None, :] < self.len[:, None]
+        b = self.buf
+        adv, cadv = b["adv"].copy(), b["cadv"].copy()
+        if mask.sum() > 0:
+            m, s = mpi_statistics_scalar(adv[mask].flatten())
+            adv[mask] = (adv[mask] - m) / (s + 1e-8)
+            cm, _ = mpi_statistics_scalar(cadv[mask].flatten())
+            cadv[mask] -= cm
+            ret_mean, cret_mean = b["ret"][mask].mean(), b["cret"][mask].mean()
+        else:
+            ret_mean = cret_mean = 0
+        res = [b["obs"], b["act"], adv, cadv, b["ret"], b["cret"], b["logp"], b["val"], b["cval"], b["cost"],
+               b["log_std"], b["mu"]]
+        res = [x[mask] for x in res]
+        return res, dict(poolm_batch_size=int(mask.sum()), poolm_ret_mean=ret_mean, poolm_cret_mean=cret_mean)
+
+    def diagnostics(self):
+        """model_sampler.py:89-133 (the keys that carry information)."""
+        t, e = self.tot, 1e-8
+        return {"msampler/samples_added": t["samples"], "msampler/rollout_H_max": self.n_episodes,
+                "msampler/rollout_H_mean": t["samples"] / (self.B + e),
+                "msampler/dyn_var_perstep": t["dyn_ep_var"] / (t["samples"] + e),
+                "msampler/cost_rate": self.path_cost.sum() / (t["samples"] + e),
+                "msampler/rew_rate": self.path_ret.sum() / (t["samples"] + e),
+                "msampler/v_mean": t["Vs"] / (t["samples"] + e), "msampler/cv_mean": t["CVs"] / (t["samples"] + e),
+                "msampler/ens_DKL": t["dkl"] / (t["samples"] + e),
+                "msampler/max_path_return": t["max_path_return"], "msampler/max_dkl": t["max_dkl"]}

@@ -1,0 +1,373 @@
+"""Generate golden vectors by running the REFERENCE's own NumPy code in the build container.
+
+Usage (build container only; /root/reference does not exist on the GPU box):
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Writes tests/golden/*.npz (data only: inputs and the reference's outputs).  The TF-graph half of the
+reference cannot run (no TensorFlow), so the model / policy objects handed to the reference's
+FakeEnv / ModelSampler are duck-typed stand-ins computing the restated forward passes of
+oracle/refcpu.py; everything downstream of them (FakeEnv.step, average_dkl, statics, ModelSampler,
+ModelBuffer, discount_cumsum, mpi_statistics_scalar, cg, CPOAgent.update_pi, CPOBuffer) is the
+reference's code, imported from /root/reference behind inert stubs for the modules it imports at the
+top of its files but never touches on these paths (tensorflow, gym, ray, mpi4py, ...).
+"""
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("CMBPO_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+if not hasattr(np, "int"):
+    np.int = int       # buffers/cpobuffer.py:135, utilities/utils.py:300
+if not hasattr(np, "bool"):
+    np.bool = bool
+
+
+class _Inert(types.ModuleType):
+    """Module-like object: any attribute is another inert object, callable, iterable, subclassable."""
+
+    def __init__(self, name="stub"):
+        super().__init__(name)
+        self.__path__ = []
+
+    def __getattr__(self, item):
+        if item.startswith("__") and item.endswith("__"):
+            raise AttributeError(item)
+        child = _InertClass
+        return child
+
+    def __call__(self, *a, **k):
+        return _Inert()
+
+
+class _InertMeta(type):
+    def __getattr__(cls, item):
+        if item.startswith("__") and item.endswith("__"):
+            raise AttributeError(item)
+        return _InertClass
+
+    def __iter__(cls):
+        return iter(())
+
+    def __contains__(cls, item):
+        return False
+
+    def __getitem__(cls, item):
+        return _InertClass
+
+
+class _InertClass(metaclass=_InertMeta):
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _InertClass()
+
+    def __getattr__(self, item):
+        if item.startswith("__") and item.endswith("__"):
+            raise AttributeError(item)
+        return _InertClass()
+
+    def __iter__(self):
+        return iter(())
+
+
+_STUB_ROOTS = {"tensorflow", "gtimer", "dotmap", "gym", "ray", "mujoco_py", "wrappers", "cv2", "safety_gym",
+               "joblib", "psutil_stub"}
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname.split(".")[0] in _STUB_ROOTS:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        return _Inert(spec.name)
+
+    def exec_module(self, module):
+        pass
+
+
+def install_stubs():
+    sys.meta_path.insert(0, _StubFinder())
+    mpi4py = types.ModuleType("mpi4py")
+
+    class _Comm:
+        def Get_rank(self):
+            return 0
+
+        def Get_size(self):
+            return 1
+
+        def Allreduce(self, x, buf, op=None):
+            buf[...] = x
+
+        def Bcast(self, x, root=0):
+            pass
+
+    class _MPI:
+        COMM_WORLD = _Comm()
+        SUM, MIN, MAX = "sum", "min", "max"
+
+    mpi4py.MPI = _MPI
+    sys.modules["mpi4py"] = mpi4py
+
+
+# ------------------------------------------------------------------------------------------------
+class _Space:
+    def __init__(self, d):
+        self.shape = (d,)
+
+
+class _TrueEnv:
+    def __init__(self, obs_dim, act_dim):
+        self.observation_space, self.action_space = _Space(obs_dim), _Space(act_dim)
+
+
+class OracleModel:
+    """Duck type of EnsembleModel (models/base_model.py) computing the restated forward."""
+
+    def __init__(self, ws, bs, sc_in, sc_out, elites):
+        self.ws, self.bs, self.sc_in, self.sc_out = ws, bs, sc_in, sc_out
+        self.is_ensemble, self.is_probabilistic = True, True
+        self.in_dim, self.out_dim = ws[0].shape[1], ws[2].shape[2] // 2
+        self.elite_inds = elites
+
+    def predict_ensemble(self, x):
+        from oracle import refcpu
+        return refcpu.ens_forward(x, self.ws, self.bs, self.sc_in, self.sc_out)
+
+
+class OraclePolicy:
+    """Duck type of CPOPolicy for the sampler (samplers/model_sampler.py:249-256,401-407)."""
+
+    class agent:
+        reward_penalized = False
+
+    def __init__(self, params, v, vc, rng):
+        self.params, self.v, self.vc, self.rng = params, v, vc, rng
+        self.eps_log = []
+
+    def reset(self):
+        pass
+
+    def get_v(self, obs):
+        from oracle import refcpu
+        return refcpu.ens_predict_mean(obs, *self.v)[:, 0]
+
+    def get_vc(self, obs):
+        from oracle import refcpu
+        return refcpu.ens_predict_mean(obs, *self.vc)[:, 0]
+
+    def get_action_outs(self, obs):
+        from oracle import refcpu
+        eps = self.rng.standard_normal((obs.shape[0], self.params[-1].shape[0])).astype(np.float32)
+        self.eps_log.append(eps)
+        out = refcpu.policy_forward(obs, self.params, eps)
+        return dict(pi=out["pi"], logp_pi=out["logp_pi"], pi_info=dict(mu=out["mu"], log_std=out["log_std"]),
+                    v=self.get_v(obs), vc=self.get_vc(obs))
+
+
+def build_world(seed, task, hidden, E=7, out_scale=1.0, q_boost=0.0):
+    """Seeded weights shared by the generator and the tests (tests rebuild them from `seed`)."""
+    from cmbpo_amd import synthetic
+    rng = np.random.default_rng(seed)
+    obs_dim, act_dim = synthetic.ENV_DIMS[task]
+    ws, bs = synthetic.ensemble_weights(rng, E, obs_dim + act_dim, hidden, 2 * (obs_dim + 1), bias_scale=0.05,
+                                        out_scale=out_scale)
+    if q_boost:
+        bs[2][:, 0, 2] += q_boost      # pushes a quaternion dim so AntSafe's z_rot < -0.7 branch fires
+    sc_in = synthetic.scaler(rng, obs_dim + act_dim, hit_clamp=False)
+    sc_out = synthetic.scaler(rng, obs_dim + 1, hit_clamp=False)
+    sc_out = (sc_out[0], (sc_out[1] * 0.01).astype(np.float32))
+    pol = synthetic.policy_params(rng, obs_dim, act_dim)
+    crit = []
+    for _ in range(2):
+        cw, cb = synthetic.ensemble_weights(rng, 3, obs_dim, 128, 1, bias_scale=0.05)
+        crit.append((cw, cb, synthetic.scaler(rng, obs_dim, hit_clamp=False),
+                     synthetic.scaler(rng, 1, hit_clamp=False)))
+    elites = [0, 2, 3, 5, 6][: max(1, E - 2)]
+    return dict(obs_dim=obs_dim, act_dim=act_dim, ws=ws, bs=bs, sc_in=sc_in, sc_out=sc_out, pol=pol,
+                v=crit[0], vc=crit[1], elites=elites)
+
+
+def gen_statics(out):
+    from models import statics
+    rng = np.random.default_rng(101)
+    n = 400
+    data = {}
+    for task, (od, ad) in (("AntSafe-v2", (29, 8)), ("HalfCheetahSafe-v2", (20, 6))):
+        obs = rng.standard_normal((n, od)).astype(np.float32)
+        act = rng.standard_normal((n, ad)).astype(np.float32)
+        nxt = (rng.standard_normal((n, od)) * 1.5).astype(np.float32)
+        nxt[:, 0] = rng.uniform(-0.2, 1.4, n).astype(np.float32)
+        # edges: z boundaries, z_rot at the threshold, non-finite entries, cost thresholds
+        nxt[0, 0], nxt[1, 0], nxt[2, 0], nxt[3, 0] = 0.2, 1.0, np.float32(0.2) - 1e-7, np.float32(1.0) + 1e-6
+        nxt[4, 0] = 0.5; nxt[4, 2] = np.sqrt(0.85); nxt[4, 3] = 0.0       # z_rot = -0.7 (approximately)
+        nxt[5, 0] = 0.5; nxt[5, 2] = 2.0
+        nxt[6, 5] = np.nan; nxt[7, 2] = np.inf; nxt[8, 0] = np.nan; nxt[9, 3] = -np.inf
+        nxt[10, -1], nxt[11, -1], nxt[12, -1] = 3.2, np.float32(3.2) + 1e-6, -4.0
+        nxt[13, -1], nxt[14, -1] = 0.2, np.float32(0.2) - 1e-8
+        with np.errstate(all="ignore"):
+            term = statics.TERMS_BY_TASK[task](obs, act, nxt)
+            cost = statics.COST_BY_TASK[task](obs, act, nxt)
+        key = task.split("-")[0]
+        data.update({f"{key}_obs": obs, f"{key}_act": act, f"{key}_next": nxt,
+                     f"{key}_term": term, f"{key}_cost": np.asarray(cost)})
+    nd = statics.no_done(obs, act, nxt)
+    data["no_done"] = nd
+    np.savez_compressed(os.path.join(out, "g1_statics.npz"), **data)
+
+
+def gen_dkl(out):
+    from models.pens.utils import average_dkl, gaussian_kl_np
+    rng = np.random.default_rng(102)
+    mu = rng.standard_normal((7, 300, 29)).astype(np.float32)
+    std = np.exp(rng.uniform(-8, 1, (7, 300, 29))).astype(np.float32)
+    std[:, 0, 0] = 0.0
+    std[2, 1, 1] = 1e-30
+    with np.errstate(all="ignore"):
+        d = average_dkl(mu, std)
+        k = gaussian_kl_np(mu[0], np.log(std[0] + 1e-3), mu[1], np.log(std[1] + 1e-3))
+    np.savez_compressed(os.path.join(out, "g2_dkl.npz"), mu=mu, std=std, average_dkl=d, pair_kl=k)
+
+
+def gen_gae_and_stats(out):
+    from utilities.utils import discount_cumsum
+    from utilities.mpi_tools import mpi_statistics_scalar
+    from utilities.trust_region import cg
+    rng = np.random.default_rng(103)
+    x32 = rng.standard_normal((50, 34)).astype(np.float32)
+    y = discount_cumsum(x32, 0.99, 0.95, axis=-1)
+    yc = discount_cumsum(x32, 0.97, 0.5, axis=-1)
+    x1 = rng.standard_normal(1000).astype(np.float32)
+    y1 = discount_cumsum(x1, 0.99, 0.95, axis=-1)
+    s = rng.standard_normal(5000).astype(np.float32) * 3 + 1
+    mean, std = mpi_statistics_scalar(s)
+    # cg on SPD operators, fixed 10 iterations (trust_region.py:32-45)
+    n = 40
+    M = rng.standard_normal((n, n)).astype(np.float32)
+    Aop = (M @ M.T / n + 0.1 * np.eye(n)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    x = cg(lambda p: (Aop @ p).astype(np.float32), b)
+    np.savez_compressed(os.path.join(out, "g3_gae_stats_cg.npz"), x32=x32, gae_r=y, gae_c=yc, x1=x1, gae_1d=y1,
+                        stat_in=s, stat_mean=mean, stat_std=std, cg_A=Aop, cg_b=b, cg_x=x)
+
+
+def run_sampler_trace(seed, task, B, T, hidden, dkl_lim, budget, mode, out_scale=1.0, q_boost=0.0, max_steps=100):
+    from buffers.modelbuffer import ModelBuffer
+    from models.fake_env import FakeEnv
+    from samplers.model_sampler import ModelSampler
+    from cmbpo_amd import synthetic
+    w = build_world(seed, task, hidden, out_scale=out_scale, q_boost=q_boost)
+    rng = np.random.default_rng(seed + 1)
+    model = OracleModel(w["ws"], w["bs"], w["sc_in"], w["sc_out"], w["elites"])
+    policy = OraclePolicy(w["pol"], w["v"], w["vc"], rng)
+    env = FakeEnv(_TrueEnv(w["obs_dim"], w["act_dim"]), task, model, True, True, False)
+    inds_log = []
+    orig = env.random_inds
+
+    def rec(size):
+        r = orig(size)
+        inds_log.append(np.asarray(r, dtype=np.int32))
+        return r
+
+    env.random_inds = rec
+    buf = ModelBuffer(batch_size=B, obs_dim=w["obs_dim"], act_dim=w["act_dim"], max_path_length=T)
+    buf.initialize({"mu": [w["act_dim"]], "log_std": [w["act_dim"]]}, gamma=0.99, lam=0.95,
+                   cost_gamma=0.97, cost_lam=0.5)
+    sampler = ModelSampler(max_path_length=T, batch_size=B, rollout_mode=mode, logger=object())
+    sampler.initialize(env, policy, buf)
+    sampler.set_rollout_dkl(dkl_lim)
+    start = synthetic.start_states(rng, B, task)
+    np.random.seed(seed)
+    sampler.reset(start)
+    alive_log, tot_log, ratio_log = [], [], []
+    with np.errstate(all="ignore"):
+        for _ in range(max_steps):
+            _, _, _, info = sampler.sample(max_samples=budget)
+            alive_log.append(buf.alive_paths.copy())
+            tot_log.append(sampler._total_samples)
+            ratio_log.append(info["alive_ratio"])
+            if budget and sampler._total_samples >= .99 * budget:
+                break
+            if info["alive_ratio"] <= 0.1:
+                break
+        dkl_acc = np.array(sampler._dyn_dkl_path, dtype=np.float64)
+        diag = sampler.finish_all_paths()
+        res, bdiag = buf.get()
+    nsteps = len(alive_log)
+    eps_pad = np.zeros((nsteps, B, w["act_dim"]), np.float32)
+    inds_pad = np.zeros((nsteps, B), np.int32)
+    n_rows = np.zeros(nsteps, np.int32)
+    for s in range(nsteps):
+        k = policy.eps_log[s].shape[0]
+        n_rows[s] = k
+        eps_pad[s, :k] = policy.eps_log[s]
+        inds_pad[s, :k] = inds_log[s]
+    names = ["obs", "act", "adv", "cadv", "ret", "cret", "logp", "val", "cval", "cost", "log_std", "mu"]
+    data = dict(seed=seed, task=task, B=B, T=T, hidden=hidden, dkl_lim=dkl_lim, budget=budget or 0, mode=mode,
+                out_scale=out_scale, q_boost=q_boost, start=start, eps=eps_pad, inds=inds_pad, n_rows=n_rows,
+                alive=np.array(alive_log), total_samples=np.array(tot_log, dtype=np.float64),
+                alive_ratio=np.array(ratio_log, dtype=np.float64),
+                dkl_acc=dkl_acc, poolm_batch_size=bdiag["poolm_batch_size"], poolm_ret_mean=bdiag["poolm_ret_mean"],
+                poolm_cret_mean=bdiag["poolm_cret_mean"])
+    for k, v in zip(names, res):
+        data["get_" + k] = v
+    for k, v in diag.items():
+        data["diag_" + k.replace("/", "__")] = np.float64(v)
+    return data
+
+
+def gen_sampler_traces(out):
+    traces = {
+        # uncertainty-limited, AntSafe terminations, budget hit mid-rollout
+        "g5_trace_ant_unc": dict(seed=7, task="AntSafe-v2", B=96, T=12, hidden=128, dkl_lim=None, budget=330,
+                                 mode="uncertainty", out_scale=1.0, q_boost=1.2),
+        # env terminations (AntSafe rule) spread over several steps, then the horizon finish
+        "g5_trace_ant_term": dict(seed=7, task="AntSafe-v2", B=96, T=8, hidden=128, dkl_lim=float("inf"),
+                                  budget=None, mode="uncertainty", out_scale=1.0, q_boost=1.2),
+        # fixed horizon ('schedule' style), no budget, HalfCheetah cost rule
+        "g5_trace_hcs_sched": dict(seed=8, task="HalfCheetahSafe-v2", B=64, T=9, hidden=128, dkl_lim=float("inf"),
+                                   budget=None, mode="schedule"),
+        # no statics entry (Hopper): never terminates, bool zero cost; tight budget
+        "g5_trace_hopper_budget": dict(seed=9, task="HopperSafe-v2", B=50, T=15, hidden=128, dkl_lim=float("inf"),
+                                       budget=333, mode="uncertainty"),
+    }
+    for name, cfg in traces.items():
+        if cfg["dkl_lim"] is None:
+            # calibrate a limit that kills a fraction of the branches over the rollout
+            # limit = median accumulated DKL after 4 steps: about half the branches die at step 4,
+            # the rest one step later (partial uncertainty deaths + terminations + budget interplay)
+            probe = run_sampler_trace(**{**cfg, "dkl_lim": float("inf"), "budget": None, "max_steps": 4})
+            acc = np.sort(probe["dkl_acc"])
+            lo, hi = int(.35 * len(acc)), int(.65 * len(acc))
+            k = lo + int(np.argmax(acc[lo + 1:hi + 1] - acc[lo:hi]))      # widest gap near the median:
+            cfg["dkl_lim"] = float(0.5 * (acc[k] + acc[k + 1]))           # no branch sits on the limit
+        data = run_sampler_trace(**cfg)
+        np.savez_compressed(os.path.join(out, name + ".npz"), **data)
+        print(name, "steps", len(data["n_rows"]), "rows/step", data["n_rows"].tolist(),
+              "samples", int(data["poolm_batch_size"]))
+
+
+def main():
+    install_stubs()
+    gen_statics(HERE)
+    gen_dkl(HERE)
+    gen_gae_and_stats(HERE)
+    gen_sampler_traces(HERE)
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

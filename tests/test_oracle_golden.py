@@ -1,0 +1,120 @@
+"""CPU: pin the oracle (oracle/refcpu.py) against golden vectors produced by the reference's own code
+(tests/golden/make_golden.py, run in the build container against /root/reference).
+
+Everything here is NumPy-vs-NumPy, so the bar is bit-exact unless a comment says otherwise.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import refcpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = ["obs", "act", "adv", "cadv", "ret", "cret", "logp", "val", "cval", "cost", "log_std", "mu"]
+
+
+def _load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+
+
+def test_g1_statics_bit_exact():
+    g = _load("g1_statics")
+    with np.errstate(all="ignore"):
+        for key, task in (("AntSafe", "AntSafe-v2"), ("HalfCheetahSafe", "HalfCheetahSafe-v2")):
+            obs, act, nxt = g[key + "_obs"], g[key + "_act"], g[key + "_next"]
+            term = refcpu.TERMS_BY_TASK[task](obs, act, nxt)
+            cost = refcpu.COST_BY_TASK[task](obs, act, nxt)
+            np.testing.assert_array_equal(term, g[key + "_term"])
+            np.testing.assert_array_equal(np.asarray(cost, np.float64), np.asarray(g[key + "_cost"], np.float64))
+            assert term.dtype == bool and term.shape == (obs.shape[0], 1)
+    # the precedence quirk: in-range z, z_rot < -0.7 -> done; out-of-range z -> never done
+    nxt, term = g["AntSafe_next"], g["AntSafe_term"][:, 0]
+    assert term[5] and not term[2] and not term[3]
+    assert term[7]           # gate 0 * z_rot(-inf) = nan -> `nan >= -0.7` is False -> done
+    assert not term[6]       # non-finite elsewhere: gate 0, finite z_rot -> not done
+    assert g["no_done"].dtype == bool and not g["no_done"].any()
+
+
+def test_g2_average_dkl_bit_exact():
+    g = _load("g2_dkl")
+    with np.errstate(all="ignore"):
+        d = refcpu.average_dkl(g["mu"], g["std"])
+        k = refcpu.gaussian_kl_np(g["mu"][0], np.log(g["std"][0] + 1e-3), g["mu"][1], np.log(g["std"][1] + 1e-3))
+    np.testing.assert_array_equal(d, g["average_dkl"])
+    np.testing.assert_array_equal(k, g["pair_kl"])
+    assert d.dtype == g["average_dkl"].dtype
+
+
+def test_g3_discount_cumsum_stats_cg():
+    g = _load("g3_gae_stats_cg")
+    y = refcpu.discount_cumsum(g["x32"], 0.99, 0.95)
+    assert y.dtype == np.float64 == g["gae_r"].dtype     # lfilter promotes float32 input to float64
+    np.testing.assert_array_equal(y, g["gae_r"])
+    np.testing.assert_array_equal(refcpu.discount_cumsum(g["x32"], 0.97, 0.5), g["gae_c"])
+    np.testing.assert_array_equal(refcpu.discount_cumsum(g["x1"], 0.99, 0.95), g["gae_1d"])
+    m, s = refcpu.mpi_statistics_scalar(g["stat_in"])
+    assert m == g["stat_mean"] and s == g["stat_std"]
+    A = g["cg_A"]
+    x = refcpu.cg(lambda p: (A @ p).astype(np.float32), g["cg_b"].copy())
+    np.testing.assert_array_equal(x, g["cg_x"])
+    # known answers: constant rewards closed form, CG exact on a 2x2 SPD system
+    c = 0.99 * 0.95
+    closed = np.array([(1 - c ** (5 - t)) / (1 - c) for t in range(5)])
+    np.testing.assert_allclose(refcpu.discount_cumsum(np.ones(5), 0.99, 0.95), closed, rtol=1e-14)
+    M = np.array([[4.0, 1.0], [1.0, 3.0]])
+    np.testing.assert_allclose(refcpu.cg(lambda p: M @ p, np.array([1.0, 2.0])), np.linalg.solve(M, [1.0, 2.0]),
+                               rtol=1e-6)
+
+
+def oracle_from_world(w, task, T, mode, dkl_lim):
+    model = lambda x: refcpu.ens_forward(x, w["ws"], w["bs"], w["sc_in"], w["sc_out"])
+    policy = lambda obs, eps: refcpu.policy_forward(obs, w["pol"], eps)
+    v = lambda obs: refcpu.ens_predict_mean(obs, *w["v"])[:, 0]
+    vc = lambda obs: refcpu.ens_predict_mean(obs, *w["vc"])[:, 0]
+    return refcpu.RolloutOracle(model, policy, v, vc, task, w["obs_dim"], w["act_dim"], T, mode, dkl_lim)
+
+
+def replay_trace(g, make_world):
+    task, B, T = str(g["task"]), int(g["B"]), int(g["T"])
+    w = make_world(int(g["seed"]), task, int(g["hidden"]), out_scale=float(g["out_scale"]),
+                   q_boost=float(g["q_boost"]))
+    orc = oracle_from_world(w, task, T, str(g["mode"]), float(g["dkl_lim"]))
+    orc.reset(g["start"])
+    budget = int(g["budget"]) or None
+    alive, totals, ratios = [], [], []
+    with np.errstate(all="ignore"):
+        for s in range(len(g["n_rows"])):
+            n = int(g["n_rows"][s])
+            ratio = orc.sample(g["eps"][s, :n], g["inds"][s, :n], max_samples=budget)
+            alive.append(orc.alive.copy())
+            totals.append(orc.tot["samples"])
+            ratios.append(ratio)
+        orc.finish_all()
+        res, diag = orc.get()
+    return orc, np.array(alive), np.array(totals), np.array(ratios), res, diag
+
+
+TRACES = ["g5_trace_ant_unc", "g5_trace_ant_term", "g5_trace_hcs_sched", "g5_trace_hopper_budget"]
+
+
+@pytest.mark.parametrize("name", TRACES)
+def test_g5_rollout_oracle_matches_reference_trace(name):
+    import sys
+    sys.path.insert(0, GOLD)
+    from make_golden import build_world
+    g = _load(name)
+    orc, alive, totals, ratios, res, diag = replay_trace(g, build_world)
+    np.testing.assert_array_equal(alive, g["alive"])                    # masks per step: bit-exact
+    np.testing.assert_array_equal(totals, g["total_samples"])
+    np.testing.assert_allclose(ratios, g["alive_ratio"], rtol=0, atol=0)
+    assert diag["poolm_batch_size"] == int(g["poolm_batch_size"])
+    for k, arr in zip(NAMES, res):
+        np.testing.assert_array_equal(arr, g["get_" + k], err_msg=k)     # same NumPy ops: bit-exact
+        assert arr.dtype == g["get_" + k].dtype, k
+    assert diag["poolm_ret_mean"] == g["poolm_ret_mean"] and diag["poolm_cret_mean"] == g["poolm_cret_mean"]
+    d = orc.diagnostics()
+    for k, v in d.items():
+        # float32 running sums in the reference (python int 0 + np.float32): order-of-accumulation level
+        np.testing.assert_allclose(v, float(g["diag_" + k.replace("/", "__")]), rtol=1e-6, err_msg=k)
+    np.testing.assert_allclose(orc.dkl_acc, g["dkl_acc"], rtol=1e-12)

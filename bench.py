@@ -1,0 +1,222 @@
+"""bench.py -- imagined env-steps/s of the MI355X-native CMBPO rollout (+ CPO update ms).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--branches B] [--task AntSafe-v2]
+
+One "step" = one full imagined-rollout phase of the reference trainer on one batch of start states:
+``ModelSampler.reset -> sample() x (maxroll-1) -> finish_all_paths -> ModelBuffer.get()``
+(algorithms/cmbpo.py:251-269, the span the reference times as `times/epoch_rollout_model`, :293),
+with the inputs (start states, weights) already resident in HBM.  metric value = imagined env-steps
+(sum of alive branches over the steps, `msampler/samples_added`) per second, whole job over all ranks.
+
+Workload at N = 1: AntSafe-v2 shapes (obs 29, act 8), 7-member 512x512 swish ensemble, 5 elites, 3+3
+critic members, 128x128 tanh policy, B = 100 000 branches per GPU, maxroll 35 (34 stored steps),
+fixed-horizon mode -- the north-star configuration ("AntSafe 7-ensemble 100k-branch rollouts at
+1 MI355X").  N > 1: every rank rolls out its own B branches (weak scaling, no data-path collective;
+the only collectives are the advantage statistics of get()).  Synthetic seeded weights / states.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+MAXROLL = 35
+
+
+class _Space:
+    def __init__(self, d):
+        self.shape = (d,)
+
+
+def build_world(seed, task, hidden=512, E=7):
+    """Seeded synthetic weights of the reference's shapes."""
+    from cmbpo_amd import synthetic
+    rng = np.random.default_rng(seed)
+    D, A = synthetic.ENV_DIMS[task]
+    ws, bs = synthetic.ensemble_weights(rng, E, D + A, hidden, 2 * (D + 1), out_scale=0.05)
+    sc_in = synthetic.scaler(rng, D + A, hit_clamp=False)
+    sc_out = synthetic.scaler(rng, D + 1, hit_clamp=False)
+    sc_out = (sc_out[0] * 0.1, (sc_out[1] * 1e-3).astype(np.float32))     # small deltas: branches survive
+    pol = synthetic.policy_params(rng, D, A)
+    crit = []
+    for _ in range(2):
+        cw, cb = synthetic.ensemble_weights(rng, 3, D, 128, 1)
+        crit.append((cw, cb, synthetic.scaler(rng, D, hit_clamp=False), synthetic.scaler(rng, 1, hit_clamp=False)))
+    return dict(obs_dim=D, act_dim=A, ws=ws, bs=bs, sc_in=sc_in, sc_out=sc_out, pol=pol, v=crit[0], vc=crit[1],
+                elites=[0, 2, 3, 5, 6])
+
+
+def build_hip(w, task, B, device, comm=None):
+    from cmbpo_amd.cpo_policy import CPOPolicy
+    from cmbpo_amd.fake_env import FakeEnv
+    from cmbpo_amd.model_sampler import ModelSampler
+    from cmbpo_amd.modelbuffer import ModelBuffer
+    from cmbpo_amd.pens import PE
+    D, A = w["obs_dim"], w["act_dim"]
+    hidden = w["ws"][1].shape[1]
+    model = PE(D + A, D + 1, hidden_dims=(hidden, hidden), num_networks=w["ws"][0].shape[0], num_elites=5,
+               loss="MSPE", use_scaler_in=True, use_scaler_out=True, device=device)
+    model.set_weights(w["ws"], w["bs"], w["sc_in"], w["sc_out"])
+    model.set_elites(w["elites"])
+    policy = CPOPolicy(_Space(D), _Space(A), a_hidden_layer_sizes=(128, 128), vf_hidden_layer_sizes=(128, 128),
+                       vf_ensemble_size=3, vf_elites=2, vf_activation="swish", vf_loss="MSE", device=device,
+                       cost_gamma=0.97, cost_lam=0.5, lam=0.95)
+    policy.actor.set_params(w["pol"])
+    policy.v.set_weights(*w["v"])
+    policy.vc.set_weights(*w["vc"])
+
+    class _Env:
+        observation_space, action_space = _Space(D), _Space(A)
+
+    env = FakeEnv(_Env(), task, model, True, True, False)
+    pool = ModelBuffer(B, D, A, MAXROLL, device=device, comm=comm)
+    pool.initialize(policy.pi_info_shapes, gamma=0.99, lam=0.95, cost_gamma=0.97, cost_lam=0.5)
+    sampler = ModelSampler(max_path_length=MAXROLL, batch_size=B, rollout_mode="schedule", comm=comm)
+    sampler.initialize(env, policy, pool)
+    return sampler, pool, env, policy
+
+
+def rollout_phase(sampler, pool, start):
+    """reset -> sample until everything is finished -> finish_all_paths -> get(); returns samples."""
+    sampler.reset(start)
+    while pool.n_alive > 0:
+        sampler.sample()
+    diag = sampler.finish_all_paths()
+    res, bdiag = pool.get(as_tensors=True)
+    return int(diag["msampler/samples_added"]), res
+
+
+def cpu_baseline(w, task, seconds=20.0):
+    """The oracle (NumPy restatement of the reference semantics, NOT TF 1.14) on the host cores."""
+    from oracle import refcpu
+    from cmbpo_amd import synthetic
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    rng = np.random.default_rng(1)
+    B = 2000
+    model = lambda x: refcpu.ens_forward(x, w["ws"], w["bs"], w["sc_in"], w["sc_out"])
+    policy = lambda obs, eps: refcpu.policy_forward(obs, w["pol"], eps)
+    v = lambda obs: refcpu.ens_predict_mean(obs, *w["v"])[:, 0]
+    vc = lambda obs: refcpu.ens_predict_mean(obs, *w["vc"])[:, 0]
+    orc = refcpu.RolloutOracle(model, policy, v, vc, task, w["obs_dim"], w["act_dim"], MAXROLL, "schedule",
+                               float("inf"))
+    start = synthetic.start_states(rng, B, task)
+    elites = np.asarray(w["elites"], np.int32)
+    t0 = time.perf_counter()
+    orc.reset(start)
+    steps = 0
+    with np.errstate(all="ignore"):
+        while orc.alive.any() and (time.perf_counter() - t0 < seconds or steps < 2):
+            n = int(orc.alive.sum())
+            orc.sample(rng.standard_normal((n, w["act_dim"])).astype(np.float32),
+                       elites[rng.integers(0, len(elites), n)])
+            steps += 1
+        orc.finish_all()
+        orc.get()
+    dt = time.perf_counter() - t0
+    return dict(value=orc.tot["samples"] / dt, unit="imagined env-steps/s", cores=int(threads), kind="port",
+                sample=f"NumPy oracle (restatement of reference semantics, not TF 1.14): B={B} branches x "
+                       f"{steps} steps of the same workload + finish/get, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--branches", type=int, default=100000, help="rollout branches per GPU")
+    ap.add_argument("--task", default="AntSafe-v2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import cmbpo_amd  # noqa: F401
+    from cmbpo_amd import _lib, synthetic
+    from cmbpo_amd.dist import Comm
+    _lib.lib()   # fail loudly if the HIP library is missing
+
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    comm = Comm.init_from_env("nccl")
+    comm.device = device
+    rank, world = comm.rank, comm.world
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    task, B = args.task, args.branches
+    w = build_world(0, task)
+    sampler, pool, env, policy = build_hip(w, task, B, device, comm if world > 1 else None)
+    rng = np.random.default_rng(100 + rank)
+    start = torch.from_numpy(synthetic.start_states(rng, B, task)).to(device)
+
+    for _ in range(args.warmup):
+        rollout_phase(sampler, pool, start)
+    env.kernel_events = []
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    samples = 0
+    for _ in range(args.steps):
+        n, _ = rollout_phase(sampler, pool, start)
+        samples += n
+    torch.cuda.synchronize()
+    comm.barrier()
+    dt = time.perf_counter() - t0
+    events, env.kernel_events = env.kernel_events, None
+
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    comm.all_reduce_max(t)
+    dt_max = float(t.item())
+    tot = comm.all_reduce_host([samples])[0]
+
+    # roofline of the dominant kernel (fused ensemble MLP forward), HIP events on the launch stream
+    D, A, E, H = w["obs_dim"], w["act_dim"], w["ws"][0].shape[0], w["ws"][1].shape[1]
+    flop_per_row = 2.0 * E * ((D + A) * H + H * H + H * 2 * (D + 1))
+    k_ms = [s.elapsed_time(e) for s, e, _ in events]
+    k_rows = [n for _, _, n in events]
+    avg_ms = float(np.mean(k_ms)) if k_ms else float("nan")
+    achieved = flop_per_row * float(np.mean(k_rows)) / (avg_ms * 1e-3) / 1e12 if k_ms else float("nan")
+
+    if rank == 0:
+        out = {
+            "metric": "imagined env-steps/sec (ensemble rollout)",
+            "value": tot / dt_max,
+            "unit": "imagined env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{task} imagined rollout: E=7 x (37->512->512->60) swish ensemble, 5 elites, "
+                                   f"3+3 critics 128x128, tanh policy 128x128, B={B} branches/GPU, maxroll 35 "
+                                   f"(34 steps), reset->sample*->finish_all_paths->get()",
+                       "branches_per_gpu": B, "horizon": MAXROLL - 1, "task": task,
+                       "samples_per_step": tot / args.steps},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "ens_mlp_kernel<512,1,swish,prob>", "avg_launch_ms": avg_ms,
+                         "launches": len(k_ms), "flop_per_branch_step": flop_per_row},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, task, seconds=args.cpu_seconds)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    comm.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,71 @@
+"""Collectives for the sharded path: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" for the CPU tests).
+
+Replaces the mpi4py wrappers of ``utilities/mpi_tools.py:43-92`` at their call sites:
+every payload is tiny (<= 2P+4 floats), so calls are fused (one all-reduce per CG / line-search step,
+one per statistics pass) and weighted by sample counts instead of assuming equal shards
+(``mpi_avg``, ``mpi_tools.py:67-69``).  Counts travel as float64 / int64, never float32
+(``mpi_tools.py:59,83`` loses exactness above 2**24 samples).
+"""
+import os
+
+import torch
+import torch.distributed as td
+
+
+class Comm:
+    def __init__(self, device=None):
+        self.enabled = td.is_available() and td.is_initialized()
+        self.rank = td.get_rank() if self.enabled else 0
+        self.world = td.get_world_size() if self.enabled else 1
+        self.device = device
+
+    @staticmethod
+    def init_from_env(backend=None):
+        """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun)."""
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1 and not td.is_initialized():
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            td.init_process_group(backend=backend)
+        return Comm()
+
+    def all_reduce_sum(self, t):
+        """In-place SUM of a (device) tensor; a view of a larger tensor is reduced through a copy."""
+        if self.world > 1:
+            if t.is_contiguous() and t.storage_offset() == 0:
+                td.all_reduce(t, op=td.ReduceOp.SUM)
+            else:
+                tmp = t.contiguous().clone()
+                td.all_reduce(tmp, op=td.ReduceOp.SUM)
+                t.copy_(tmp)
+        return t
+
+    def all_reduce_max(self, t):
+        if self.world > 1:
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+        return t
+
+    def all_gather_i32(self, row):
+        """row: int32[k] on the device -> int32[world, k] (rank-major)."""
+        row = row.contiguous().clone()
+        out = torch.empty((self.world, row.numel()), dtype=row.dtype, device=row.device)
+        if self.world > 1:
+            td.all_gather_into_tensor(out.view(-1), row)
+        else:
+            out[0] = row
+        return out
+
+    def all_reduce_host(self, values):
+        """SUM of a few host scalars (float64)."""
+        if self.world == 1:
+            return [float(v) for v in values]
+        dev = self.device if self.device is not None else ("cuda" if td.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        return t.cpu().tolist()
+
+    def barrier(self):
+        if self.world > 1:
+            td.barrier()

@@ -40,6 +40,8 @@ class FakeEnv:
         self._task_id = _lib.TASK_IDS.get(task, _lib.TASK_DEFAULT)
         self._rng = np.random.default_rng(seed)
         self.device = model.device
+        # bench.py sets this to a list to collect (start, end) HIP events around the dominant kernel
+        self.kernel_events = None
 
     @property
     def observation_space(self):
@@ -70,9 +72,16 @@ class FakeEnv:
             mean, var = scratch
         lib = _lib.lib()
         stream = _lib.current_stream()
+        ev = None
+        if self.kernel_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()      # same stream the kernel is launched on (torch's current stream)
         _lib.check(lib.cmbpo_ens_forward(self._model.mlp.handle, _lib.ptr(obs), self.obs_dim,
                                          _lib.ptr(act), self.act_dim, _lib.ptr(row_idx), None, n, B,
                                          _lib.ptr(mean), _lib.ptr(var), stream), "cmbpo_ens_forward")
+        if ev is not None:
+            ev[1].record()
+            self.kernel_events.append((ev[0], ev[1], n))
         _lib.check(lib.cmbpo_fakeenv_post(self._task_id, E, self.obs_dim, self.act_dim, _lib.ptr(mean),
                                           _lib.ptr(var), B, _lib.ptr(obs), _lib.ptr(act),
                                           _lib.ptr(model_inds), _lib.ptr(row_idx), None, n,

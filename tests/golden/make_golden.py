@@ -366,8 +366,130 @@ def main():
     gen_dkl(HERE)
     gen_gae_and_stats(HERE)
     gen_sampler_traces(HERE)
+    gen_update_pi(HERE)
     print("golden vectors written to", HERE)
 
 
+
+
+# ------------------------------------------------------------------------------------------------
+# G7: the reference's CPOAgent.update_pi driven by a fake session evaluating the restated graph
+# ------------------------------------------------------------------------------------------------
+def make_update_batch(rng, n, obs_dim, act_dim, hidden, cost_p, cadv_scale, T):
+    from oracle import refupdate
+    from cmbpo_amd import synthetic
+    params = np.concatenate([p.reshape(-1) for p in synthetic.policy_params(rng, obs_dim, act_dim, hidden)])
+    params = (params + rng.standard_normal(params.shape) * 0.02).astype(np.float32)
+    obs = rng.standard_normal((n, obs_dim)).astype(np.float32)
+    g0 = refupdate.PolicyGraph(obs_dim, act_dim, dict(obs=obs, act=np.zeros((n, act_dim)), adv=np.zeros(n),
+                                                      cadv=np.zeros(n), logp_old=np.zeros(n), cost=np.zeros(n),
+                                                      mu_old=np.zeros((n, act_dim)),
+                                                      log_std_old=np.zeros((n, act_dim))), hidden=hidden)
+    import torch
+    with torch.no_grad():
+        mu, ls = g0._mu(torch.as_tensor(params))
+    mu, ls = mu.numpy(), ls.numpy()
+    act = (mu + rng.standard_normal(mu.shape).astype(np.float32) * np.exp(ls)).astype(np.float32)
+    batch = dict(obs=obs, act=act, adv=rng.standard_normal(n).astype(np.float32),
+                 cadv=(rng.standard_normal(n) * cadv_scale).astype(np.float32),
+                 cost=(rng.random(n) < cost_p).astype(np.float32), mu_old=mu.astype(np.float32),
+                 log_std_old=np.tile(ls[None], (n, 1)).astype(np.float32))
+    g1 = refupdate.PolicyGraph(obs_dim, act_dim, {**batch, "logp_old": np.zeros(n)}, hidden=hidden)
+    with torch.no_grad():
+        batch["logp_old"] = g1.logp(torch.as_tensor(params)).numpy().astype(np.float32)
+    return params, batch
+
+
+def gen_update_pi(out):
+    from policies.cpo_policy import CPOAgent
+    from oracle import refupdate
+    obs_dim, act_dim, hidden, n, T = 6, 3, 16, 256, 20
+    K = {k: object() for k in ("flat_g", "flat_b", "v_ph", "hvp", "get", "set", "pi_loss", "surr_cost", "d_kl",
+                               "cur_cret_avg")}
+
+    class Logger:
+        def __init__(self):
+            self.stored = {}
+
+        def log(self, *a, **k):
+            pass
+
+        def store(self, **kw):
+            self.stored.update(kw)
+
+    class FakeSession:
+        def __init__(self, graph, params):
+            self.g, self.p = graph, np.asarray(params, np.float32).copy()
+            self.calls = dict(hvp=0, evals=0)
+
+        def run(self, fetches, feed_dict=None):
+            if fetches is K["hvp"]:
+                self.calls["hvp"] += 1
+                return self.g.hvp(self.p, feed_dict[K["v_ph"]], 0.1)
+            if fetches is K["get"]:
+                return self.p.copy()
+            if fetches is K["set"]:
+                self.p = np.asarray(feed_dict[K["v_ph"]], np.float32).copy()
+                return None
+            if isinstance(fetches, list) and len(fetches) == 5:
+                g, b, lo, sc = self.g.grads(self.p)
+                return [g, b, np.float32(lo), np.float32(sc), np.float32(float(self.g.cur_cret_avg()))]
+            if isinstance(fetches, list) and len(fetches) == 3:
+                self.calls["evals"] += 1
+                return [np.float32(t) for t in self.g.evals(self.p)]
+            raise KeyError(fetches)
+
+    scenarios = [   # (name, cost_p, cadv_scale, cost_lim, constrained, real_cost, seed)
+        ("feasible", 0.05, 1.0, 10.0, True, 3.0, 700),
+        ("violating", 0.9, 1.0, 10.0, True, 25.0, 701),
+        ("violating_hard", 1.0, 0.02, 2.0, True, 30.0, 702),
+        ("zero_costgrad", 0.0, 0.0, 10.0, True, 1.0, 703),
+        ("unconstrained_ls_fail", 0.5, 1.0, 10.0, False, 10.0, 704),
+        ("feasible_tight", 0.45, 3.0, 10.0, True, 9.0, 705),
+        ("slightly_violating", 0.56, 10.0, 10.0, True, 10.5, 706),
+        ("unconstrained", 0.5, 1.0, 10.0, False, 10.0, 707),
+    ]
+    data = dict(obs_dim=obs_dim, act_dim=act_dim, hidden=hidden, T=T, names=np.array([s[0] for s in scenarios]))
+    for si, (name, cost_p, cadv_scale, cost_lim, constrained, real_cost, seed) in enumerate(scenarios):
+        rng = np.random.default_rng(seed)
+        params, batch = make_update_batch(rng, n, obs_dim, act_dim, hidden, cost_p, cadv_scale, T)
+        graph = refupdate.PolicyGraph(obs_dim, act_dim, batch, max_path_length=T, hidden=hidden)
+        sess = FakeSession(graph, params)
+        agent = CPOAgent(constrained=constrained, reward_penalized=False, objective_penalized=False,
+                         learn_penalty=False, penalty_param_loss=False, learn_margin=True, c_gamma=0.97,
+                         max_path_length=T)
+        logger = Logger()
+        agent.set_logger(logger)
+        agent.prepare_session(sess)
+        real_buf = [real_cost] * 300
+        agent.prepare_update(dict(flat_g=K["flat_g"], flat_b=K["flat_b"], v_ph=K["v_ph"], hvp=K["hvp"],
+                                  get_pi_params=K["get"], set_pi_params=K["set"], pi_loss=K["pi_loss"],
+                                  surr_cost=K["surr_cost"], d_kl=K["d_kl"], target_kl=0.01, cost_lim=cost_lim,
+                                  cur_cret_avg=K["cur_cret_avg"], real_cost_buf=real_buf))
+        agent.margin = 0.002 * si
+        with np.errstate(all="ignore"):
+            agent.update_pi({})
+        st = logger.stored
+        pre = f"s{si}_"
+        data[pre + "params"] = params
+        for k, v in batch.items():
+            data[pre + "b_" + k] = v
+        data[pre + "cost_lim"], data[pre + "constrained"], data[pre + "real_cost"] = cost_lim, constrained, real_cost
+        data[pre + "margin_in"] = 0.002 * si
+        data[pre + "new_params"] = sess.p
+        data[pre + "hvp_calls"], data[pre + "eval_calls"] = sess.calls["hvp"], sess.calls["evals"]
+        for k in ("Optim_A", "Optim_B", "Optim_c", "Optim_q", "Optim_r", "Optim_s", "Optim_Lam", "Optim_Nu",
+                  "Margin", "OptimCase", "BacktrackIters"):
+            data[pre + k] = np.float64(st[k])
+        print("update_pi", name, "case", int(st["OptimCase"]), "backtrack", int(st["BacktrackIters"]),
+              "hvp calls", sess.calls["hvp"], "evals", sess.calls["evals"],
+              "moved", bool(np.any(sess.p != params)))
+    np.savez_compressed(os.path.join(out, "g7_update_pi.npz"), **data)
+
+
 if __name__ == "__main__":
-    main()
+    if "--update-only" in sys.argv:
+        install_stubs()
+        gen_update_pi(HERE)
+    else:
+        main()

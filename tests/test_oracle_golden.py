@@ -118,3 +118,77 @@ def test_g5_rollout_oracle_matches_reference_trace(name):
         # float32 running sums in the reference (python int 0 + np.float32): order-of-accumulation level
         np.testing.assert_allclose(v, float(g["diag_" + k.replace("/", "__")]), rtol=1e-6, err_msg=k)
     np.testing.assert_allclose(orc.dkl_acc, g["dkl_acc"], rtol=1e-12)
+
+
+def test_g7_update_pi_logic_matches_reference():
+    """oracle.refupdate.update_pi vs the reference's CPOAgent.update_pi (recorded with a fake session that
+    evaluates the same restated graph): case selection, dual variables, step, backtracking, margin."""
+    from oracle import refupdate
+    g = _load("g7_update_pi")
+    D, A, H, T = int(g["obs_dim"]), int(g["act_dim"]), int(g["hidden"]), int(g["T"])
+    cases = set()
+    for si, name in enumerate(g["names"]):
+        pre = f"s{si}_"
+        batch = {k: g[pre + "b_" + k] for k in ("obs", "act", "adv", "cadv", "logp_old", "cost", "mu_old",
+                                                 "log_std_old")}
+        graph = refupdate.PolicyGraph(D, A, batch, max_path_length=T, hidden=H)
+        params = g[pre + "params"]
+        calls = dict(hvp=0, evals=0)
+
+        def Hx(v):
+            calls["hvp"] += 1
+            return graph.hvp(params, v, 0.1)
+
+        def set_and_eval(p):
+            calls["evals"] += 1
+            return graph.evals(np.asarray(p, np.float32))
+
+        def grads():
+            gg, bb, lo, sc = graph.grads(params)
+            return gg, bb, lo, sc, float(graph.cur_cret_avg())
+
+        agent = refupdate.AgentState(T, constrained=bool(g[pre + "constrained"]))
+        agent.margin = float(g[pre + "margin_in"])
+        with np.errstate(all="ignore"):
+            new_params, info = refupdate.update_pi(agent, dict(grads=grads, Hx=Hx, set_and_eval=set_and_eval), params,
+                                                   0.01, float(g[pre + "cost_lim"]), [float(g[pre + "real_cost"])] * 300)
+        assert info["OptimCase"] == int(g[pre + "OptimCase"]), name
+        assert info["BacktrackIters"] == int(g[pre + "BacktrackIters"]), name
+        assert calls["hvp"] == int(g[pre + "hvp_calls"]) and calls["evals"] == int(g[pre + "eval_calls"]), name
+        for k in ("Optim_A", "Optim_B", "Optim_c", "Optim_q", "Optim_r", "Optim_s", "Optim_Lam", "Optim_Nu", "Margin"):
+            np.testing.assert_allclose(np.float64(info[k]), g[pre + k], rtol=1e-12, atol=0, err_msg=f"{name}:{k}")
+        np.testing.assert_array_equal(np.asarray(new_params, np.float32), g[pre + "new_params"], err_msg=name)
+        cases.add(info["OptimCase"])
+    assert cases == {0, 1, 2, 3, 4}
+
+
+def test_oracle_graph_analytic_cross_checks():
+    """The TF half has no reference outputs to pin against ('parity unpinned'): check the restated graph
+    against central finite differences (float64) and the explicit Fisher form instead."""
+    import sys
+    import torch
+    sys.path.insert(0, GOLD)
+    from make_golden import make_update_batch
+    from oracle import refupdate
+    rng = np.random.default_rng(3)
+    D, A, H, n, T = 5, 2, 16, 64, 10
+    params, batch = make_update_batch(rng, n, D, A, H, 0.3, 1.0, T)
+    graph = refupdate.PolicyGraph(D, A, batch, max_path_length=T, hidden=H, dtype=torch.float64, ent_reg=0.01)
+    p64 = params.astype(np.float64)
+    gg, bb, lo, sc = graph.grads(p64)
+    v = rng.standard_normal(p64.shape)
+    h = 1e-6
+    fd = lambda f: (f(p64 + h * v) - f(p64 - h * v)) / (2 * h)
+    ev = lambda q: graph.evals(q)
+    np.testing.assert_allclose(np.dot(gg, v), fd(lambda q: ev(q)[1]), rtol=1e-6)
+    np.testing.assert_allclose(np.dot(bb, v), fd(lambda q: ev(q)[2]), rtol=1e-6, atol=1e-10)
+    # Hessian of the KL by finite differences of its gradient direction: v^T H v
+    kl = lambda q: ev(q)[0]
+    h2 = 1e-4
+    vHv_fd = (kl(p64 + h2 * v) - 2 * kl(p64) + kl(p64 - h2 * v)) / h2 ** 2
+    hv = graph.hvp(p64, v, damping=0.0)
+    np.testing.assert_allclose(np.dot(v, hv), vHv_fd, rtol=1e-5)
+    # at theta = theta_old (mu_old produced by the same parameters) the exact Hessian is the Fisher form
+    # (mu_old was rounded to float32, so a (mu_old - mu) * d2mu term of order 1e-7 remains)
+    np.testing.assert_allclose(graph.fisher_vp(p64, v, 0.1), graph.hvp(p64, v, 0.1), rtol=1e-4, atol=1e-6)
+    assert abs(kl(p64)) < 1e-6      # KL(p || p) = 0 (up to the 1e-8 in the denominator)

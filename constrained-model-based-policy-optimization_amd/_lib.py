@@ -80,6 +80,25 @@ SIGNATURES.update({
     "cmbpo_buffer_flatten": (_i, [_rp, _p, _p, C.POINTER(C.c_void_p), _p]),
 })
 
+
+
+class PiBatchStruct(C.Structure):
+    """ctypes image of ``cmbpo_pi_batch_t``."""
+    _fields_ = [("n", C.c_int32), ("obs_dim", C.c_int32), ("act_dim", C.c_int32)] + \
+               [(k, C.c_void_p) for k in ("obs", "act", "adv", "cadv", "logp_old", "cost", "mu_old", "logstd_old")]
+
+
+_bp = C.POINTER(PiBatchStruct)
+SIGNATURES.update({
+    "cmbpo_pi_create": (_i, [C.POINTER(_p), _i, _i, _i]),
+    "cmbpo_pi_destroy": (None, [_p]),
+    "cmbpo_pi_num_params": (_i, [_p]),
+    "cmbpo_pi_set_params": (_i, [_p, _p, _p]),
+    "cmbpo_pi_loss_grad": (_i, [_p, _bp, _i, _p, _p, _p]),
+    "cmbpo_pi_fvp": (_i, [_p, _bp, _p, _p, _p]),
+    "cmbpo_pi_eval": (_i, [_p, _bp, _p, _p]),
+})
+
 _lib = None
 
 

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .cpo_update import CPOAgent, PolicyOps, _NullLogger
 from .pens import PE, EnsembleMLP, _to_dev
 
 
@@ -32,6 +33,7 @@ class GaussianActor:
         self.sizes = [int(np.prod(s)) for s in self.shapes]
         self.n_params = int(sum(self.sizes))
         self.params = None
+        self.version = 0      # bumped by set_params so dependants can re-sync lazily
 
     def set_params(self, params):
         """params: list of 7 arrays, or one flat vector in the same order (trust_region.py:21-25)."""
@@ -44,6 +46,7 @@ class GaussianActor:
                 off += sz
         self.params = [np.ascontiguousarray(p, dtype=np.float32).reshape(s) for p, s in zip(params, self.shapes)]
         w0, b0, w1, b1, w2, b2, ls = self.params
+        self.version += 1
         self.mlp.load([w0[None], w1[None], w2[None]], [b0[None], b1[None], b2[None]], log_std=ls)
 
     def get_flat_params(self):
@@ -56,11 +59,6 @@ class GaussianActor:
             _lib.ptr(out["pi"]), _lib.ptr(out["logp_pi"]), _lib.ptr(out["mu"]), _lib.ptr(out["log_std"]),
             _lib.current_stream()), "cmbpo_policy_forward")
         return out
-
-
-class _Agent:
-    """The attributes of CPOAgent the samplers read (policies/cpo_policy.py:105-108)."""
-    reward_penalized = False
 
 
 class CPOPolicy:
@@ -87,10 +85,15 @@ class CPOPolicy:
         self.gamma = kw.get("discount", 0.99)          # cpo_policy.py:362 reads 'discount'
         self.max_path_length = kw.get("max_path_length", 1)
         self.real_c_buffer = [self.cost_lim] * 300     # cpo_policy.py:356
-        self.logger = logger
-        self.agent = _Agent()
+        self.logger = logger if logger is not None else _NullLogger()
+        self.comm = kw.get("comm", None)
         self.actor = GaussianActor(self.obs_dim, self.act_dim, self.hidden_sizes_a, device)
         self.device = self.actor.device
+        # cpo_policy.py:366-374: the agent's hyper-parameters
+        self.agent = CPOAgent(constrained=self.constrain_cost, learn_margin=True, c_gamma=self.cost_gamma,
+                              max_path_length=self.max_path_length, ent_reg=self.ent_reg)
+        self.agent.set_logger(self.logger)
+        self.ops = PolicyOps(self.obs_dim, self.act_dim, self.actor.hidden, self.device, comm=self.comm)
         common = dict(hidden_dims=self.hidden_sizes_c, num_networks=self.vf_ensemble,
                       num_elites=self.vf_elites, loss="MSE", activation="swish",
                       use_scaler_in=True, use_scaler_out=True, device=self.device)
@@ -105,7 +108,77 @@ class CPOPolicy:
         pass
 
     def set_logger(self, logger):
+        """cpo_policy.py:588-598: the logger is shared with the agent."""
         self.logger = logger
+        self.agent.set_logger(logger)
+
+    def set_params(self, params):
+        """Actor parameters ([W0,b0,W1,b1,W2,b2,log_std] or one flat vector) -> rollout + update handles."""
+        self.actor.set_params(params)
+        self._sync_ops()
+
+    def _sync_ops(self):
+        if getattr(self, "_ops_version", None) != self.actor.version:
+            self.ops.set_params(self.actor.get_flat_params())
+            self._ops_version = self.actor.version
+
+    # -- update (policies/cpo_policy.py:600-656, 733-754, 837-845) ------------------------------------
+    def _bind(self, buf_inputs):
+        # buf_fields order (cpo_policy.py:472-477): obs, act, adv, cadv, ret, cret, logp_old, v, vc, cost, log_std, mu
+        obs, act, adv, cadv, _ret, _cret, logp_old, _v, _vc, cost, log_std, mu = buf_inputs
+        self.ops.bind(obs, act, adv, cadv, logp_old, cost, mu, log_std)
+
+    def update_real_c(self, buf_inputs):
+        """cpo_policy.py:733-737: running window of real epoch costs that drives the margin."""
+        cost = buf_inputs[9]
+        m = float(cost.mean()) if isinstance(cost, torch.Tensor) else float(np.mean(cost))
+        self.real_c_buffer.append(m * self.max_path_length)
+        self.real_c_buffer.pop(0)
+
+    def update_policy(self, buf_inputs):
+        """cpo_policy.py:600-656: pre-measures, CPOAgent.update_pi, post-measures and deltas."""
+        self._sync_ops()
+        self._bind(buf_inputs)
+        pre = self.agent.measures(self.ops)
+        self.logger.store(LossPi=pre["LossPi"], SurrCost=pre["SurrCost"], SurrAdv=pre["SurrAdv"],
+                          Entropy=pre["Entropy"])
+        cost = buf_inputs[9]
+        cur_cost = (float(cost.mean()) if isinstance(cost, torch.Tensor) else float(np.mean(cost))) * self.max_path_length
+        if cur_cost - self.cost_lim > 0 and self.agent.cares_about_cost:
+            self.logger.log('Warning! Safety constraint is already violated.', 'red')
+        info = self.agent.update_pi(self.ops, self.target_kl, self.cost_lim, self.real_c_buffer)
+        # the accepted (or restored) parameters now live in ops; mirror them into the rollout actor
+        self.actor.set_params(self.ops.get_params())
+        self._ops_version = self.actor.version
+        post = self.agent.measures(self.ops)
+        deltas = {k + "Delta": post[k] - pre[k] for k in ("LossPi", "SurrCost", "SurrAdv")}
+        self.logger.store(KL=post["KL"], **deltas)
+        return info
+
+    def run_diagnostics(self, buf_inputs):
+        """cpo_policy.py:739-754 without the critic losses (critic training is SURVEY §8f row N2)."""
+        self._sync_ops()
+        self._bind(buf_inputs)
+        m = self.agent.measures(self.ops)
+        return dict(LossPi=m["LossPi"], SurrCost=m["SurrCost"], Entropy=m["Entropy"])
+
+    def compute_DKL(self, obs_batch, mu_batch, logstd_batch):
+        """cpo_policy.py:837-845: mean KL(current || stored) per archived epoch ([n_epochs, B, .] or 2-D)."""
+        self._sync_ops()
+
+        def one(o, m, l):
+            n = o.shape[0]
+            z = np.zeros(n, np.float32)
+            self.ops.bind(o, np.zeros((n, self.act_dim), np.float32), z, z, z, z, m, l)
+            s = self.ops.evals()
+            return s[3] / s[0]
+        if len(obs_batch.shape) == 3:
+            return np.array([one(o, m, l) for o, m, l in zip(obs_batch, mu_batch, logstd_batch)])
+        return one(obs_batch, mu_batch, logstd_batch)
+
+    def update_critic(self, buf_inputs, train_vc=True, **kwargs):
+        raise NotImplementedError("critic training (policies/cpo_policy.py:658-731) is SURVEY §8(f) row N2, outside "
+                                  "this path; load critic weights with policy.v.set_weights / policy.vc.set_weights.")
 
     # -- acting ----------------------------------------------------------------------------
     def format_obs(self, obs):

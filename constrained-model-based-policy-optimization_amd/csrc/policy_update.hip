@@ -1,0 +1,593 @@
+// Fused policy-MLP kernels for the CPO trust-region update (gfx950, fp32-exact MFMA).
+//
+// Replaces the TF graph fragments of the reference that every CG iteration / line-search trial
+// re-evaluates with a full feed of the batch:
+//   policies/cpo_policy.py:522-543   ratio, surr_adv, surr_cost, pi_loss, cur_cret_avg
+//   policies/cpo_policy.py:549,555   flat_g = grad(pi_loss), flat_b = grad(surr_cost)     (MODE_GRAD)
+//   utilities/trust_region.py:15-19  hessian_vector_product(d_kl, pi_params)             (MODE_FVP)
+//   policies/cpo_policy.py:278-280   [d_kl, pi_loss, surr_cost] at trial parameters       (MODE_EVAL)
+//   network/ac_network.py:26-55,99-123  tanh MLP, gaussian_likelihood, gaussian_kl
+//
+// One persistent workgroup per CU walks tiles of 32 samples (samples on the MFMA lanes).  Per tile:
+// forward chain (as ens_mlp.hip), then either the JVP chain + Fisher cotangent (FVP) or the loss
+// cotangent (GRAD), then the backward chain with the transposed-packed weights, and finally the
+// weight-gradient products sum_b x[b]^T d[b] as MFMAs whose K dimension is the sample index.  Weight
+// gradients stay in registers across all tiles of the workgroup and are flushed once with float
+// atomics (contiguous 128-B segments); nothing but the batch is read from HBM.
+//
+// The FVP is the Gauss-Newton / Fisher form  mean_n J^T diag(1/(var_old+eps)) J v  (+ the log_std
+// diagonal): it equals TF's double back-prop of d_kl whenever mu_old == mu(theta), which holds during
+// CG because the buffer's mu / log_std were produced by the current policy.
+#include "common.h"
+#include "mfma_tile.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int BB = 32;          // samples per tile
+constexpr int HID = 128;
+constexpr int KGH = HID / 8;    // 16
+constexpr int RS = HID + 4;     // row stride of the [b][n] images (conflict-free ds_write_b128 / ds_read_b32)
+constexpr int RED_LD = BB + 1;
+
+enum { MODE_EVAL = 0, MODE_GRAD = 1, MODE_FVP = 2 };
+
+struct PiDims {
+  int D, A, in_pad, kg0, a_kpad, kga, n_it;  // n_it = row tiles of W0 (1 or 2)
+  int oW0, ob0, oW1, ob1, oW2, ob2, ols, P;
+};
+
+struct PiPack {          // device pointers into the handle's blob
+  const f32x4 *F0, *F1, *F2, *B1, *B2;
+  const float *b0, *b1, *b2, *ls;
+};
+
+struct PiArgs {
+  PiDims d;
+  PiPack w;   // parameters
+  PiPack v;   // packed direction (FVP only)
+  int n;
+  const float *obs, *act, *adv, *cadv, *logp_old, *cost, *mu_old, *ls_old;
+  int which;        // GRAD: 0 -> cotangent of pi_loss (-adv), 1 -> cotangent of surr_cost (+cadv)
+  float *vec;       // [P]  raw sums (not divided by n)
+  double *sums;     // [8]  n, sum ratio*adv, sum ratio*cadv, sum kl, sum cost
+};
+
+// ---- packing (device side, so set_params / FVP directions never visit the host) -------------------
+// dst[((nt*kg + g)*64 + lane)*4 + s] = src[n*sn + k*sk] for n = nt*32 + (lane&31) < n_lim, k = 8g + 4(lane>>5) + s < k_lim
+__global__ void pack_kernel(float *dst, const float *src, int n_lim, int k_lim, int sn, int sk, int kg, int n_tiles) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = n_tiles * kg * 256;
+  if (idx >= total) return;
+  const int s = idx & 3, lane = (idx >> 2) & 63, g = (idx >> 8) % kg, nt = (idx >> 8) / kg;
+  const int n = nt * 32 + (lane & 31), k = 8 * g + 4 * (lane >> 5) + s;
+  dst[idx] = (n < n_lim && k < k_lim) ? src[(size_t)n * sn + (size_t)k * sk] : 0.0f;
+}
+
+__global__ void pack_vec_kernel(float *dst, const float *src, int n, int n_pad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pad) dst[i] = (i < n) ? src[i] : 0.0f;
+}
+
+// ---- tile helpers -------------------------------------------------------------------------------------
+__device__ __forceinline__ void zero(f32x16 &a) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+}
+
+// accumulator tile (rows n_base.., cols b) -> T-layout float4 [n/4][BB] and/or row layout [b][stride]
+template <bool T, bool R>
+__device__ __forceinline__ void store_tile(const f32x16 &v, int n_base, f32x4 *ldsT, float *ldsR, int strideR, int lane) {
+  const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n = n_base + 8 * q + 4 * h;
+    f32x4 x;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) x[s] = v[4 * q + s];
+    if (T) ldsT[(n >> 2) * BB + j] = x;
+    if (R) *reinterpret_cast<f32x4 *>(ldsR + j * strideR + n) = x;
+  }
+}
+
+__device__ __forceinline__ f32x16 load_tile_T(const f32x4 *ldsT, int n_base, int lane) {
+  const int j = lane & 31, h = lane >> 5;
+  f32x16 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 x = ldsT[((n_base + 8 * q + 4 * h) >> 2) * BB + j];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v[4 * q + s] = x[s];
+  }
+  return v;
+}
+
+__device__ __forceinline__ f32x16 load_bias(const float *b, int n_base, int lane) {
+  const int h = lane >> 5;
+  f32x16 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 x = *reinterpret_cast<const f32x4 *>(b + n_base + 8 * q + 4 * h);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v[4 * q + s] = x[s];
+  }
+  return v;
+}
+
+// D[i][j] += sum_b X[b][i0 + i] * Y[b][j0 + j]   (K = the 32 samples of the tile)
+__device__ __forceinline__ void wgrad_tile(f32x16 &acc, const float *X, int sx, int i0, const float *Y, int sy, int j0,
+                                           int lane) {
+  const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int s2 = 0; s2 < BB / 2; ++s2) {
+    const int b = 2 * s2 + h;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(X[b * sx + i0 + i], Y[b * sy + j0 + i], acc, 0, 0, 0);
+  }
+}
+
+// sum over the 32 lanes that share h (the sample index) -> valid in lane j == 0 of each half
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads, 1) void pi_kernel(const PiArgs p) {
+  extern __shared__ f32x4 smem4[];
+  const PiDims d = p.d;
+  float *sm = reinterpret_cast<float *>(smem4);
+  // LDS map (floats); every region is a multiple of 4 floats
+  float *xT = sm;                              // [in_pad/4][BB] float4
+  float *h1T = xT + d.in_pad * BB;             // [32][BB] float4
+  float *h2T = h1T + HID * BB;
+  float *u1T = h2T + HID * BB;                 // dh1 (T) -- later d1R (row layout, BB*RS floats)
+  float *u2T = u1T + BB * RS;                  // dh2 (T), then delta2 (T)
+  float *wT = u2T + HID * BB;                  // cotangent on mu, [a_kpad/4][BB] float4; GRAD/EVAL scratch [a][b]
+  float *xR = wT + 32 * BB;                    // [BB][in_pad + 4]
+  float *h1R = xR + BB * (d.in_pad + 4);       // [BB][RS]
+  float *h2R = h1R + BB * RS;
+  float *d2R = h2R + BB * RS;                  // delta2 rows -- first the split-K reduction image (4*32*33 floats)
+  float *wR = d2R + BB * RS;                   // [BB][36]
+  float *d1R = u1T;
+  float *red = d2R;
+  const int XS = d.in_pad + 4;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int n_tiles = (p.n + BB - 1) / BB;
+
+  // persistent accumulators
+  f32x16 gW1[4], gW0[2], gW2, gb1p, gb0p;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) zero(gW1[t]);
+  zero(gW0[0]); zero(gW0[1]); zero(gW2); zero(gb1p); zero(gb0p);
+  float gb2p[4] = {0, 0, 0, 0}, glsp[4] = {0, 0, 0, 0};   // per (a = tid/32 + 8*it) partials over this thread's b
+  double s_n = 0, s_ra = 0, s_rc = 0, s_kl = 0, s_cost = 0;
+
+  // zero the padded cotangent rows once (a in [A, 32)): nothing else ever writes them
+  for (int i = tid; i < 32 * BB; i += kThreads) wT[i] = 0.0f;
+  for (int i = tid; i < BB * 36; i += kThreads) wR[i] = 0.0f;
+  __syncthreads();
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int row0 = tile * BB;
+    // ---- stage x: T-layout (B operand) and row layout (weight-gradient operand) ------------------
+    for (int i = tid; i < d.in_pad * BB; i += kThreads) {
+      const int b = i / d.in_pad, k = i - b * d.in_pad;
+      const int r = row0 + b;
+      const float v = (r < p.n && k < d.D) ? p.obs[(size_t)r * d.D + k] : 0.0f;
+      xT[((k >> 2) * BB + b) * 4 + (k & 3)] = v;
+      xR[b * XS + k] = v;
+    }
+    __syncthreads();
+    // ---- forward ------------------------------------------------------------------------------------
+    f32x16 acc[1][1];
+    zero(acc[0][0]);
+    mfma_layer<1, 1>(p.w.F0 + (size_t)wave * d.kg0 * 64, 0, 0, d.kg0, reinterpret_cast<f32x4 *>(xT), lane, acc);
+    {
+      const f32x16 bv = load_bias(p.w.b0, wave * 32, lane);
+      f32x16 hv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hv[r] = tanhf(acc[0][0][r] + bv[r]);
+      store_tile<true, true>(hv, wave * 32, reinterpret_cast<f32x4 *>(h1T), h1R, RS, lane);
+    }
+    __syncthreads();
+    zero(acc[0][0]);
+    mfma_layer<1, 1>(p.w.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, reinterpret_cast<f32x4 *>(h1T), lane, acc);
+    {
+      const f32x16 bv = load_bias(p.w.b1, wave * 32, lane);
+      f32x16 hv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hv[r] = tanhf(acc[0][0][r] + bv[r]);
+      store_tile<true, true>(hv, wave * 32, reinterpret_cast<f32x4 *>(h2T), h2R, RS, lane);
+    }
+    __syncthreads();
+
+    if constexpr (MODE == MODE_FVP) {
+      // ---- JVP chain: dh1 = (1-h1^2)(x dW0 + db0) ; dh2 = (1-h2^2)(dh1 W1 + h1 dW1 + db1) -----------
+      zero(acc[0][0]);
+      mfma_layer<1, 1>(p.v.F0 + (size_t)wave * d.kg0 * 64, 0, 0, d.kg0, reinterpret_cast<f32x4 *>(xT), lane, acc);
+      {
+        const f32x16 bv = load_bias(p.v.b0, wave * 32, lane);
+        const f32x16 hh = load_tile_T(reinterpret_cast<f32x4 *>(h1T), wave * 32, lane);
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = (1.0f - hh[r] * hh[r]) * (acc[0][0][r] + bv[r]);
+        store_tile<true, false>(o, wave * 32, reinterpret_cast<f32x4 *>(u1T), nullptr, 0, lane);
+      }
+      __syncthreads();
+      zero(acc[0][0]);
+      mfma_layer<1, 1>(p.w.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, reinterpret_cast<f32x4 *>(u1T), lane, acc);
+      mfma_layer<1, 1>(p.v.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, reinterpret_cast<f32x4 *>(h1T), lane, acc);
+      {
+        const f32x16 bv = load_bias(p.v.b1, wave * 32, lane);
+        const f32x16 hh = load_tile_T(reinterpret_cast<f32x4 *>(h2T), wave * 32, lane);
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = (1.0f - hh[r] * hh[r]) * (acc[0][0][r] + bv[r]);
+        store_tile<true, false>(o, wave * 32, reinterpret_cast<f32x4 *>(u2T), nullptr, 0, lane);
+      }
+      __syncthreads();
+      // dmu = dh2 W2 + h2 dW2 (+ db2): K split over the 4 waves
+      zero(acc[0][0]);
+      mfma_layer<1, 1>(p.w.F2, 0, wave * 4, wave * 4 + 4, reinterpret_cast<f32x4 *>(u2T), lane, acc);
+      mfma_layer<1, 1>(p.v.F2, 0, wave * 4, wave * 4 + 4, reinterpret_cast<f32x4 *>(h2T), lane, acc);
+    } else {
+      // mu = h2 W2 (+ b2): K split over the 4 waves
+      zero(acc[0][0]);
+      mfma_layer<1, 1>(p.w.F2, 0, wave * 4, wave * 4 + 4, reinterpret_cast<f32x4 *>(h2T), lane, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int a = (r & 3) + 8 * (r >> 2) + 4 * h;
+      red[(wave * 32 + a) * RED_LD + j] = acc[0][0][r];
+    }
+    __syncthreads();
+
+    // ---- element phase over (a, b): this thread owns b = tid & 31, a = tid/32 + 8*it ------------------
+    const int eb = tid & 31, er = row0 + eb;
+    const bool valid = er < p.n;
+    float z_[4], mu_[4], term_[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int a = (tid >> 5) + 8 * it;
+      z_[it] = mu_[it] = term_[it] = 0.0f;
+      if (a < d.A) {
+        float m = red[(0 * 32 + a) * RED_LD + eb];
+        m += red[(1 * 32 + a) * RED_LD + eb];
+        m += red[(2 * 32 + a) * RED_LD + eb];
+        m += red[(3 * 32 + a) * RED_LD + eb];
+        if constexpr (MODE == MODE_FVP) {
+          m += p.v.b2[a];
+          float cot = 0.0f;
+          if (valid) {
+            // d2 KL / d mu^2 = 1 / (exp(2 ls_old) + eps)   (network/ac_network.py:52-53)
+            const float v1 = expf(2.0f * p.ls_old[(size_t)er * d.A + a]) + 1e-8f;
+            cot = m / v1;
+            glsp[it] += 2.0f * expf(2.0f * p.w.ls[a]) / v1;     // d2 KL / d log_std^2
+          }
+          wT[((a >> 2) * BB + eb) * 4 + (a & 3)] = cot;
+          wR[eb * 36 + a] = cot;
+          gb2p[it] += cot;
+        } else {
+          m += p.w.b2[a];
+          mu_[it] = m;
+          if (valid) {
+            const float ls = p.w.ls[a];
+            const float sd = expf(ls) + 1e-8f;
+            const float z = (p.act[(size_t)er * d.A + a] - m) / sd;
+            z_[it] = z;
+            term_[it] = -0.5f * (z * z + 2.0f * ls + 1.8378770664093453f);   // gaussian_likelihood :46-48
+          }
+          u1T[a * BB + eb] = term_[it];   // scratch image [a][b] (u1T is idle outside the FVP)
+        }
+      }
+    }
+    if constexpr (MODE != MODE_FVP) {
+      __syncthreads();
+      float logp = 0.0f;
+      for (int a = 0; a < d.A; ++a) logp += u1T[a * BB + eb];
+      const float ratio = valid ? expf(logp - p.logp_old[er]) : 0.0f;        // cpo_policy.py:522
+      const float adv = valid ? p.adv[er] : 0.0f, cadv = valid ? p.cadv[er] : 0.0f;
+      if (tid < 32 && valid) {
+        s_n += 1.0;
+        s_ra += (double)(ratio * adv);
+        s_rc += (double)(ratio * cadv);
+        s_cost += (double)p.cost[er];
+      }
+      __syncthreads();   // every thread has read the scratch image before it is overwritten
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int a = (tid >> 5) + 8 * it;
+        if (a < d.A) {
+          if constexpr (MODE == MODE_EVAL) {
+            if (valid) {
+              // gaussian_kl(mu, log_std, mu_old, log_std_old), ac_network.py:50-55
+              const float ls = p.w.ls[a], lso = p.ls_old[(size_t)er * d.A + a];
+              const float dm = p.mu_old[(size_t)er * d.A + a] - mu_[it];
+              const float pre = 0.5f * ((dm * dm + expf(2.0f * ls)) / (expf(2.0f * lso) + 1e-8f) - 1.0f) + lso - ls;
+              s_kl += (double)pre;
+            }
+          } else {
+            const float wgt = (p.which == 0) ? -adv : cadv;
+            const float ls = p.w.ls[a];
+            const float sd = expf(ls);
+            const float inv = 1.0f / (sd + 1e-8f);
+            const float cot = wgt * ratio * z_[it] * inv;                    // d logp / d mu = z / (sd + eps)
+            wT[((a >> 2) * BB + eb) * 4 + (a & 3)] = cot;
+            wR[eb * 36 + a] = cot;
+            gb2p[it] += cot;
+            glsp[it] += wgt * ratio * (z_[it] * z_[it] * sd * inv - 1.0f);  // d logp / d log_std
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if constexpr (MODE == MODE_EVAL) continue;
+
+    // ---- backward: delta2 = (W2 cot) (1-h2^2) ; delta1 = (W1 delta2) (1-h1^2) --------------------------
+    zero(acc[0][0]);
+    mfma_layer<1, 1>(p.w.B2 + (size_t)wave * d.kga * 64, 0, 0, d.kga, reinterpret_cast<f32x4 *>(wT), lane, acc);
+    {
+      const f32x16 hh = load_tile_T(reinterpret_cast<f32x4 *>(h2T), wave * 32, lane);
+      f32x16 o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[r] = (1.0f - hh[r] * hh[r]) * acc[0][0][r];
+        gb1p[r] += o[r];
+      }
+      store_tile<true, true>(o, wave * 32, reinterpret_cast<f32x4 *>(u2T), d2R, RS, lane);
+    }
+    __syncthreads();
+    zero(acc[0][0]);
+    mfma_layer<1, 1>(p.w.B1 + (size_t)wave * KGH * 64, 0, 0, KGH, reinterpret_cast<f32x4 *>(u2T), lane, acc);
+    {
+      const f32x16 hh = load_tile_T(reinterpret_cast<f32x4 *>(h1T), wave * 32, lane);
+      f32x16 o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[r] = (1.0f - hh[r] * hh[r]) * acc[0][0][r];
+        gb0p[r] += o[r];
+      }
+      store_tile<false, true>(o, wave * 32, nullptr, d1R, RS, lane);
+    }
+    __syncthreads();
+    // ---- weight gradients: K = the tile's samples ---------------------------------------------------
+#pragma unroll
+    for (int J = 0; J < 4; ++J) wgrad_tile(gW1[J], h1R, RS, wave * 32, d2R, RS, J * 32, lane);
+    wgrad_tile(gW0[0], xR, XS, 0, d1R, RS, wave * 32, lane);
+    if (d.n_it > 1) wgrad_tile(gW0[1], xR, XS, 32, d1R, RS, wave * 32, lane);
+    wgrad_tile(gW2, h2R, RS, wave * 32, wR, 36, 0, lane);
+    __syncthreads();
+  }
+
+  // ---- flush -------------------------------------------------------------------------------------------
+  if constexpr (MODE != MODE_EVAL) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+      for (int J = 0; J < 4; ++J)
+        atomicAdd(&p.vec[d.oW1 + (wave * 32 + row) * HID + J * 32 + j], gW1[J][r]);
+      if (row < d.D) atomicAdd(&p.vec[d.oW0 + row * HID + wave * 32 + j], gW0[0][r]);
+      if (d.n_it > 1 && 32 + row < d.D) atomicAdd(&p.vec[d.oW0 + (32 + row) * HID + wave * 32 + j], gW0[1][r]);
+      if (j < d.A) atomicAdd(&p.vec[d.oW2 + (wave * 32 + row) * d.A + j], gW2[r]);
+      const float s1 = half_sum(gb1p[r]), s0 = half_sum(gb0p[r]);
+      if (j == 0) {
+        atomicAdd(&p.vec[d.ob1 + wave * 32 + row], s1);
+        atomicAdd(&p.vec[d.ob0 + wave * 32 + row], s0);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int a = (tid >> 5) + 8 * it;
+      const float sb = half_sum(gb2p[it]), sl = half_sum(glsp[it]);
+      if (a < d.A && (tid & 31) == 0) {
+        atomicAdd(&p.vec[d.ob2 + a], sb);
+        if constexpr (MODE == MODE_GRAD) atomicAdd(&p.vec[d.ols + a], sl);
+        else atomicAdd(&p.vec[d.ols + a], sl * p.v.ls[a]);
+      }
+    }
+  }
+  if constexpr (MODE != MODE_FVP) {
+    // tid < 32 hold the per-sample sums; s_kl is spread over every thread
+    __shared__ double sd[4];
+    const double kl = wave_sum_d(s_kl);
+    if (lane == 0) sd[wave] = kl;
+    __syncthreads();
+    if (wave == 0) {
+      const double n = wave_sum_d(s_n), ra = wave_sum_d(s_ra), rc = wave_sum_d(s_rc), c = wave_sum_d(s_cost);
+      if (lane == 0) {
+        atomicAdd(&p.sums[0], n);
+        atomicAdd(&p.sums[1], ra);
+        atomicAdd(&p.sums[2], rc);
+        atomicAdd(&p.sums[3], sd[0] + sd[1] + sd[2] + sd[3]);
+        atomicAdd(&p.sums[4], c);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+struct cmbpo_pi {
+  PiDims d;
+  float *blob;       // parameters pack | direction pack | vec [P] | sums (8 doubles)
+  size_t pack_floats;
+  size_t off_F0, off_F1, off_F2, off_B1, off_B2, off_b0, off_b1, off_b2, off_ls;
+  int n_cu;
+  bool has_params;
+};
+
+namespace {
+
+PiPack pack_ptrs(const cmbpo_pi *h, const float *base) {
+  PiPack k;
+  k.F0 = reinterpret_cast<const f32x4 *>(base + h->off_F0);
+  k.F1 = reinterpret_cast<const f32x4 *>(base + h->off_F1);
+  k.F2 = reinterpret_cast<const f32x4 *>(base + h->off_F2);
+  k.B1 = reinterpret_cast<const f32x4 *>(base + h->off_B1);
+  k.B2 = reinterpret_cast<const f32x4 *>(base + h->off_B2);
+  k.b0 = base + h->off_b0; k.b1 = base + h->off_b1; k.b2 = base + h->off_b2; k.ls = base + h->off_ls;
+  return k;
+}
+
+int do_pack(const cmbpo_pi *h, float *dst, const float *flat, hipStream_t s) {
+  const PiDims &d = h->d;
+  auto pk = [&](size_t off, const float *src, int n_lim, int k_lim, int sn, int sk, int kg, int nt) {
+    const int total = nt * kg * 256;
+    hipLaunchKernelGGL(pack_kernel, dim3(cmbpo_ceil_div(total, 256)), dim3(256), 0, s, dst + off, src, n_lim, k_lim, sn,
+                       sk, kg, nt);
+  };
+  // forward packs: A[i = out unit][k = in unit] = W[k][i]
+  pk(h->off_F0, flat + d.oW0, HID, d.D, 1, HID, d.kg0, 4);
+  pk(h->off_F1, flat + d.oW1, HID, HID, 1, HID, KGH, 4);
+  pk(h->off_F2, flat + d.oW2, d.A, HID, 1, d.A, KGH, 1);
+  // backward packs: A[i = in unit][k = out unit] = W[i][k]
+  pk(h->off_B1, flat + d.oW1, HID, HID, HID, 1, KGH, 4);
+  pk(h->off_B2, flat + d.oW2, HID, d.A, d.A, 1, d.kga, 4);
+  hipLaunchKernelGGL(pack_vec_kernel, dim3(1), dim3(128), 0, s, dst + h->off_b0, flat + d.ob0, HID, HID);
+  hipLaunchKernelGGL(pack_vec_kernel, dim3(1), dim3(128), 0, s, dst + h->off_b1, flat + d.ob1, HID, HID);
+  hipLaunchKernelGGL(pack_vec_kernel, dim3(1), dim3(32), 0, s, dst + h->off_b2, flat + d.ob2, d.A, 32);
+  hipLaunchKernelGGL(pack_vec_kernel, dim3(1), dim3(32), 0, s, dst + h->off_ls, flat + d.ols, d.A, 32);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+size_t lds_bytes(const PiDims &d) {
+  const size_t f = (size_t)d.in_pad * BB + 2 * HID * BB + BB * RS + HID * BB + 32 * BB + BB * (d.in_pad + 4) +
+                   3 * BB * RS + BB * 36;
+  return f * sizeof(float);
+}
+
+template <int MODE>
+int launch_pi(cmbpo_pi *h, PiArgs &a, hipStream_t s) {
+  auto kern = pi_kernel<MODE>;
+  static size_t attr_bytes = 0;   // the kernel also has a few bytes of static LDS: ask for what is needed
+  const size_t lds = lds_bytes(h->d);
+  if (lds > attr_bytes) {
+    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_bytes = lds;
+  }
+  const int tiles = cmbpo_ceil_div(a.n, BB);
+  const int grid = tiles < h->n_cu ? tiles : h->n_cu;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, s, a);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+int fill_args(cmbpo_pi *h, const cmbpo_pi_batch_t *b, PiArgs &a, const char *who) {
+  CMBPO_REQUIRE(h != nullptr && b != nullptr, "%s: NULL handle / batch", who);
+  if (!h->has_params) { cmbpo_set_error("%s: parameters not set", who); return CMBPO_ESTATE; }
+  CMBPO_REQUIRE(b->obs_dim == h->d.D && b->act_dim == h->d.A, "%s: batch dims (%d,%d) != policy dims (%d,%d)", who,
+                b->obs_dim, b->act_dim, h->d.D, h->d.A);
+  CMBPO_REQUIRE(b->n >= 1, "%s: empty batch", who);
+  CMBPO_REQUIRE(b->obs != nullptr, "%s: obs is NULL", who);
+  a.d = h->d;
+  a.w = pack_ptrs(h, h->blob);
+  a.v = pack_ptrs(h, h->blob + h->pack_floats);
+  a.n = b->n;
+  a.obs = b->obs; a.act = b->act; a.adv = b->adv; a.cadv = b->cadv; a.logp_old = b->logp_old; a.cost = b->cost;
+  a.mu_old = b->mu_old; a.ls_old = b->logstd_old;
+  return CMBPO_OK;
+}
+
+}  // namespace
+
+extern "C" int cmbpo_pi_create(cmbpo_pi_t **out, int obs_dim, int hidden, int act_dim) {
+  CMBPO_REQUIRE(out != nullptr, "cmbpo_pi_create: out is NULL");
+  CMBPO_REQUIRE(hidden == HID, "cmbpo_pi_create: hidden must be 128 (got %d)", hidden);
+  CMBPO_REQUIRE(obs_dim >= 1 && obs_dim <= 64, "cmbpo_pi_create: obs_dim %d not in [1, 64]", obs_dim);
+  CMBPO_REQUIRE(act_dim >= 1 && act_dim <= 32, "cmbpo_pi_create: act_dim %d not in [1, 32]", act_dim);
+  cmbpo_pi *h = new (std::nothrow) cmbpo_pi();
+  if (!h) { cmbpo_set_error("cmbpo_pi_create: out of host memory"); return CMBPO_ENOMEM; }
+  PiDims &d = h->d;
+  d.D = obs_dim; d.A = act_dim;
+  d.in_pad = (obs_dim + 7) / 8 * 8; d.kg0 = d.in_pad / 8;
+  d.a_kpad = (act_dim + 7) / 8 * 8; d.kga = d.a_kpad / 8;
+  d.n_it = (obs_dim + 31) / 32;
+  d.oW0 = 0; d.ob0 = obs_dim * HID; d.oW1 = d.ob0 + HID; d.ob1 = d.oW1 + HID * HID; d.oW2 = d.ob1 + HID;
+  d.ob2 = d.oW2 + HID * act_dim; d.ols = d.ob2 + act_dim; d.P = d.ols + act_dim;
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += (n + 3) / 4 * 4; return o; };
+  h->off_F0 = take((size_t)4 * d.kg0 * 256); h->off_F1 = take((size_t)4 * KGH * 256); h->off_F2 = take((size_t)KGH * 256);
+  h->off_B1 = take((size_t)4 * KGH * 256); h->off_B2 = take((size_t)4 * d.kga * 256);
+  h->off_b0 = take(HID); h->off_b1 = take(HID); h->off_b2 = take(32); h->off_ls = take(32);
+  h->pack_floats = off;
+  h->has_params = false;
+  hipDeviceProp_t prop;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    cmbpo_set_error("cmbpo_pi_create: cannot query the device");
+    delete h;
+    return CMBPO_EHIP;
+  }
+  h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hipMalloc(reinterpret_cast<void **>(&h->blob), 2 * off * sizeof(float)) != hipSuccess) {
+    cmbpo_set_error("cmbpo_pi_create: hipMalloc failed");
+    delete h;
+    return CMBPO_ENOMEM;
+  }
+  *out = h;
+  return CMBPO_OK;
+}
+
+extern "C" void cmbpo_pi_destroy(cmbpo_pi_t *h) {
+  if (!h) return;
+  if (h->blob) (void)hipFree(h->blob);
+  delete h;
+}
+
+extern "C" int cmbpo_pi_num_params(const cmbpo_pi_t *h) { return h ? h->d.P : -1; }
+
+extern "C" int cmbpo_pi_set_params(cmbpo_pi_t *h, const float *d_flat, void *stream) {
+  CMBPO_REQUIRE(h != nullptr && d_flat != nullptr, "cmbpo_pi_set_params: NULL argument");
+  if (int rc = do_pack(h, h->blob, d_flat, (hipStream_t)stream)) return rc;
+  h->has_params = true;
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_pi_loss_grad(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, int which, float *d_vec, double *d_sums,
+                                  void *stream) {
+  PiArgs a{};
+  if (int rc = fill_args(h, b, a, "cmbpo_pi_loss_grad")) return rc;
+  CMBPO_REQUIRE(which == 0 || which == 1, "cmbpo_pi_loss_grad: which must be 0 (pi_loss) or 1 (surr_cost)");
+  CMBPO_REQUIRE(b->act && b->adv && b->cadv && b->logp_old && b->cost && d_vec && d_sums, "cmbpo_pi_loss_grad: NULL buffer");
+  hipStream_t s = (hipStream_t)stream;
+  CMBPO_HIP_CHECK(hipMemsetAsync(d_vec, 0, (size_t)h->d.P * sizeof(float), s));
+  CMBPO_HIP_CHECK(hipMemsetAsync(d_sums, 0, 8 * sizeof(double), s));
+  a.which = which; a.vec = d_vec; a.sums = d_sums;
+  return launch_pi<MODE_GRAD>(h, a, s);
+}
+
+extern "C" int cmbpo_pi_fvp(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, const float *d_v, float *d_vec, void *stream) {
+  PiArgs a{};
+  if (int rc = fill_args(h, b, a, "cmbpo_pi_fvp")) return rc;
+  CMBPO_REQUIRE(b->logstd_old && d_v && d_vec, "cmbpo_pi_fvp: NULL buffer");
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = do_pack(h, h->blob + h->pack_floats, d_v, s)) return rc;
+  CMBPO_HIP_CHECK(hipMemsetAsync(d_vec, 0, (size_t)h->d.P * sizeof(float), s));
+  a.vec = d_vec; a.sums = nullptr;
+  return launch_pi<MODE_FVP>(h, a, s);
+}
+
+extern "C" int cmbpo_pi_eval(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, double *d_sums, void *stream) {
+  PiArgs a{};
+  if (int rc = fill_args(h, b, a, "cmbpo_pi_eval")) return rc;
+  CMBPO_REQUIRE(b->act && b->adv && b->cadv && b->logp_old && b->cost && b->mu_old && b->logstd_old && d_sums,
+                "cmbpo_pi_eval: NULL buffer");
+  hipStream_t s = (hipStream_t)stream;
+  CMBPO_HIP_CHECK(hipMemsetAsync(d_sums, 0, 8 * sizeof(double), s));
+  a.vec = nullptr; a.sums = d_sums;
+  return launch_pi<MODE_EVAL>(h, a, s);
+}

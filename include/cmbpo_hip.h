@@ -241,6 +241,57 @@ int cmbpo_buffer_moments(const cmbpo_rollout_t *r, int pass, double *d_stats, vo
 int cmbpo_buffer_flatten(const cmbpo_rollout_t *r, const int32_t *d_offsets,
                          const double *d_stats, float *const *h_out12, void *stream);
 
+/* ------------------------------------------------------------------------ *
+ * CPO trust-region update: the policy-graph fetches of CPOAgent.update_pi
+ * (policies/cpo_policy.py:153-300) as fused HIP kernels.  All results are RAW
+ * SUMS over the samples of this call (the caller divides by the global sample
+ * count after an all-reduce, instead of mpi_avg's equal-shard assumption,
+ * utilities/mpi_tools.py:67-69).  Parameter vectors are flat float32[P] in the
+ * order of get_vars('pi') (network/ac_network.py:35-36): W0[obs,128], b0,
+ * W1[128,128], b1, W2[128,act], b2, log_std.
+ * ------------------------------------------------------------------------ */
+typedef struct cmbpo_pi cmbpo_pi_t;
+
+typedef struct cmbpo_pi_batch {   /* the actor feed (actor_phs, cpo_policy.py:479-487) */
+  int32_t n, obs_dim, act_dim;
+  const float *obs;        /* [n,obs]                                       */
+  const float *act;        /* [n,act]                                       */
+  const float *adv;        /* [n]                                           */
+  const float *cadv;       /* [n]                                           */
+  const float *logp_old;   /* [n]                                           */
+  const float *cost;       /* [n]   cur_cost_ph                             */
+  const float *mu_old;     /* [n,act] pi_info 'mu'                          */
+  const float *logstd_old; /* [n,act] pi_info 'log_std'                     */
+} cmbpo_pi_batch_t;
+
+int cmbpo_pi_create(cmbpo_pi_t **out, int obs_dim, int hidden, int act_dim);
+void cmbpo_pi_destroy(cmbpo_pi_t *h);
+int cmbpo_pi_num_params(const cmbpo_pi_t *h);
+
+/* set_pi_params (utilities/trust_region.py:21-25, cpo_policy.py:559): d_flat is
+ * a DEVICE vector; packing into MFMA fragment order happens on the device. */
+int cmbpo_pi_set_params(cmbpo_pi_t *h, const float *d_flat, void *stream);
+
+/* flat_g / flat_b with their losses (cpo_policy.py:169-171, 522-555):
+ * which = 0: d_vec = sum_n grad(-ratio*adv)   (divide by N, subtract ent_reg on
+ *            the log_std block, to get flat_g); which = 1: sum_n grad(ratio*cadv).
+ * d_sums[8] = {n, sum ratio*adv, sum ratio*cadv, -, sum cost}. */
+int cmbpo_pi_loss_grad(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, int which,
+                       float *d_vec, double *d_sums, void *stream);
+
+/* hessian_vector_product(d_kl, pi_params) (utilities/trust_region.py:15-19) in
+ * its Gauss-Newton / Fisher form: d_vec = sum_n J^T diag(1/(exp(2 ls_old)+1e-8))
+ * J v on the MLP block and sum_n 2 exp(2 ls)/(exp(2 ls_old)+1e-8) * v on log_std.
+ * The caller divides by N and adds damping_coeff * v (cpo_policy.py:550-552). */
+int cmbpo_pi_fvp(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, const float *d_v,
+                 float *d_vec, void *stream);
+
+/* [d_kl, pi_loss, surr_cost] at the current parameters (set_and_eval,
+ * cpo_policy.py:278-280): d_sums[8] = {n, sum ratio*adv, sum ratio*cadv,
+ * sum_n sum_a kl, sum cost}. */
+int cmbpo_pi_eval(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, double *d_sums,
+                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,150 @@
+"""GPU parity of the CPO update kernels (loss/grad, Fisher-vector product, line-search eval) and of the
+whole update_policy against the oracle (torch-CPU autograd restatement of the TF graph + the update_pi
+logic pinned by golden G7).
+
+Tolerances (fp32, sums over N samples in a different order than the oracle):
+  * gradients / FVP: |d| <= 1e-3*|ref| + 3e-5*max|ref|;  scalar losses / KL: rtol 2e-4, atol 1e-6;
+  * full update: same OptimCase and BacktrackIters, duals (lam, nu) rtol 2e-2 (ten CG iterations amplify
+    rounding), accepted parameters within 2e-2 of the oracle's step norm.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, GOLD)
+
+from oracle import refupdate  # noqa: E402
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _close(got, ref, rtol=1e-3, arel=3e-5, msg=""):
+    np.testing.assert_allclose(got, ref, rtol=rtol, atol=arel * float(np.max(np.abs(ref))) + 1e-12, err_msg=msg)
+
+
+def _setup(D, A, n, seed, cost_p=0.3, cadv_scale=1.0, T=35):
+    from make_golden import make_update_batch
+    from cmbpo_amd.cpo_update import PolicyOps
+    rng = np.random.default_rng(seed)
+    params, batch = make_update_batch(rng, n, D, A, 128, cost_p, cadv_scale, T)
+    # move off theta_old a little so ratio != 1 and KL != 0 are exercised too
+    graph = refupdate.PolicyGraph(D, A, batch, max_path_length=T, hidden=128)
+    ops = PolicyOps(D, A, 128, device="cuda:0")
+    ops.set_params(params)
+    ops.bind(batch["obs"], batch["act"], batch["adv"], batch["cadv"], batch["logp_old"], batch["cost"],
+             batch["mu_old"], batch["log_std_old"])
+    return rng, params, batch, graph, ops
+
+
+@pytest.mark.parametrize("D,A,n", [(29, 8, 1037), (20, 6, 64), (47, 17, 500), (21, 3, 31)])
+def test_loss_grad_fvp_eval_match_oracle(hip_lib, D, A, n):
+    _need_gpu()
+    rng, params, batch, graph, ops = _setup(D, A, n, seed=D * 100 + A)
+    for shift in (0.0, 0.03):
+        p = (params + shift * rng.standard_normal(params.shape)).astype(np.float32)
+        ops.set_params(p)
+        g_ref, b_ref, lo_ref, sc_ref = graph.grads(p)
+        g, sg = ops.loss_grad(0)
+        b, sb = ops.loss_grad(1)
+        assert sg[0] == n and sb[0] == n
+        _close(g, g_ref, msg="flat_g")
+        _close(b, b_ref, msg="flat_b")
+        np.testing.assert_allclose(-sg[1] / n, lo_ref, rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(sg[2] / n, sc_ref, rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(sg[4] / n, float(batch["cost"].mean()), rtol=1e-6)
+        kl_ref, lo2, sc2 = graph.evals(p)
+        s = ops.evals()
+        np.testing.assert_allclose(s[3] / n, kl_ref, rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(-s[1] / n, lo2, rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(s[2] / n, sc2, rtol=2e-4, atol=1e-6)
+    # Fisher-vector product at theta_old (where it equals TF's double back-prop of d_kl)
+    ops.set_params(params)
+    for k in range(3):
+        v = rng.standard_normal(params.shape).astype(np.float32)
+        if k == 2:
+            v[:] = 0
+            v[-A:] = 1.0          # log_std block only
+        hv = ops.fvp(v) + np.float32(0.1) * v
+        _close(hv, graph.hvp(params, v, 0.1), msg=f"hvp {k}")
+        _close(hv, graph.fisher_vp(params, v, 0.1), msg=f"fisher {k}")
+
+
+def test_fvp_is_linear_and_symmetric(hip_lib):
+    """Size-independent properties at the bench size: H(a u + b v) = a Hu + b Hv, u.Hv = v.Hu, v.Hv >= 0."""
+    _need_gpu()
+    rng, params, batch, graph, ops = _setup(29, 8, 50000, seed=9)
+    u = rng.standard_normal(params.shape).astype(np.float32)
+    v = rng.standard_normal(params.shape).astype(np.float32)
+    hu, hv = ops.fvp(u), ops.fvp(v)
+    huv = ops.fvp((2 * u - 3 * v).astype(np.float32))
+    _close(huv, 2 * hu - 3 * hv, rtol=2e-3, arel=1e-4)
+    np.testing.assert_allclose(np.dot(u, hv), np.dot(v, hu), rtol=2e-3)
+    assert np.dot(v, hv) >= 0 and np.dot(u, hu) >= 0
+
+
+SCENARIOS = [   # name, cost_p, cadv_scale, cost_lim, constrained, real_cost, seed
+    ("feasible", 0.05, 1.0, 10.0, True, 3.0, 11),
+    ("violating", 0.9, 1.0, 10.0, True, 25.0, 12),
+    ("zero_costgrad", 0.0, 0.0, 10.0, True, 1.0, 13),
+    ("unconstrained", 0.5, 1.0, 10.0, False, 10.0, 14),
+    ("feasible_tight", 0.3, 3.0, 10.0, True, 9.0, 15),
+]
+
+
+@pytest.mark.parametrize("name,cost_p,cadv_scale,cost_lim,constrained,real_cost,seed", SCENARIOS)
+def test_update_policy_matches_oracle(hip_lib, name, cost_p, cadv_scale, cost_lim, constrained, real_cost, seed):
+    _need_gpu()
+    from make_golden import make_update_batch
+    from cmbpo_amd.cpo_policy import CPOPolicy
+    D, A, n, T = 29, 8, 4000, 35
+    rng = np.random.default_rng(seed)
+    params, batch = make_update_batch(rng, n, D, A, 128, cost_p, cadv_scale, T)
+
+    class _Space:
+        def __init__(self, d):
+            self.shape = (d,)
+
+    pol = CPOPolicy(_Space(D), _Space(A), a_hidden_layer_sizes=(128, 128), vf_hidden_layer_sizes=(128, 128),
+                    vf_ensemble_size=3, vf_elites=2, vf_activation="swish", vf_loss="MSE", device="cuda:0",
+                    constrain_cost=constrained, cost_lim=cost_lim, target_kl=0.01, max_path_length=T)
+    pol.set_params(params)
+    pol.real_c_buffer = [real_cost] * 300
+    z = np.zeros(n, np.float32)
+    buf = [batch["obs"], batch["act"], batch["adv"], batch["cadv"], z, z, batch["logp_old"], z, z, batch["cost"],
+           batch["log_std_old"], batch["mu_old"]]
+    info = pol.update_policy(buf)
+    new_params = pol.actor.get_flat_params()
+
+    graph = refupdate.PolicyGraph(D, A, batch, max_path_length=T, hidden=128)
+    agent = refupdate.AgentState(T, constrained=constrained)
+
+    def grads():
+        g, b, lo, sc = graph.grads(params)
+        return g, b, lo, sc, float(graph.cur_cret_avg())
+
+    ref_params, ref = refupdate.update_pi(
+        agent, dict(grads=grads, Hx=lambda v: graph.hvp(params, v, 0.1),
+                    set_and_eval=lambda p: graph.evals(np.asarray(p, np.float32))),
+        params, 0.01, cost_lim, [real_cost] * 300)
+    assert info["OptimCase"] == ref["OptimCase"], name
+    assert info["BacktrackIters"] == ref["BacktrackIters"] and info["accepted"] == ref["accepted"], name
+    for k in ("Optim_c", "Optim_q", "Optim_r", "Optim_s", "Optim_Lam", "Optim_Nu", "Margin"):
+        np.testing.assert_allclose(float(info[k]), float(ref[k]), rtol=2e-2, atol=1e-7, err_msg=f"{name}:{k}")
+    step_norm = float(np.linalg.norm(ref["step"])) + 1e-12
+    assert float(np.linalg.norm(info["step"] - ref["step"])) <= 2e-2 * step_norm, name
+    assert float(np.linalg.norm(new_params - ref_params)) <= 2e-2 * step_norm + 1e-6, name
+    st = pol.logger.stored
+    for k in ("LossPi", "SurrCost", "SurrAdv", "Entropy", "KL", "LossPiDelta", "SurrCostDelta", "Optim_A", "OptimCase",
+              "BacktrackIters"):
+        assert k in st, k
+    if ref["accepted"]:
+        assert float(st["KL"]) <= 0.01 * 1.05

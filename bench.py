@@ -93,6 +93,45 @@ def rollout_phase(sampler, pool, start):
     return int(diag["msampler/samples_added"]), res
 
 
+def time_update(policy, res, n, reps=3):
+    """CPOPolicy.update_policy on the first n samples of a get() list (device tensors); median ms."""
+    buf = [x[:n].contiguous() for x in res]
+    p0 = policy.actor.get_flat_params()
+    times, info = [], None
+    for _ in range(reps + 1):
+        policy.set_params(p0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        info = policy.update_policy(buf)
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+    policy.set_params(p0)
+    return float(np.median(times[1:])), info
+
+
+def cpu_update_baseline(w, res, n):
+    """One CPO update of the oracle (torch-CPU autograd graph + update_pi) on n samples; ms."""
+    from oracle import refupdate
+    host = [x[:n].cpu().numpy() for x in res]
+    obs, act, adv, cadv, _, _, logp, _, _, cost, ls, mu = host
+    D, A = w["obs_dim"], w["act_dim"]
+    graph = refupdate.PolicyGraph(D, A, dict(obs=obs, act=act, adv=adv, cadv=cadv, logp_old=logp, cost=cost,
+                                             mu_old=mu, log_std_old=ls), max_path_length=MAXROLL)
+    params = np.concatenate([p.reshape(-1) for p in w["pol"]]).astype(np.float32)
+    agent = refupdate.AgentState(MAXROLL, constrained=True)
+
+    def grads():
+        g, b, lo, sc = graph.grads(params)
+        return g, b, lo, sc, float(graph.cur_cret_avg())
+
+    t0 = time.perf_counter()
+    with np.errstate(all="ignore"):
+        refupdate.update_pi(agent, dict(grads=grads, Hx=lambda v: graph.hvp(params, v, 0.1),
+                                        set_and_eval=lambda p: graph.evals(np.asarray(p, np.float32))),
+                            params, 0.01, 10.0, [10.0] * 300)
+    return (time.perf_counter() - t0) * 1e3
+
+
 def cpu_baseline(w, task, seconds=20.0):
     """The oracle (NumPy restatement of the reference semantics, NOT TF 1.14) on the host cores."""
     from oracle import refcpu
@@ -174,6 +213,13 @@ def main():
     dt = time.perf_counter() - t0
     events, env.kernel_events = env.kernel_events, None
 
+    # Metric B: CPO trust-region update (update_policy, algorithms/cmbpo.py:357) on the rollout's samples
+    _, res = rollout_phase(sampler, pool, start)
+    n_full = int(res[0].shape[0])
+    n50 = min(50000, n_full)
+    upd_ms_50k, upd_info = time_update(policy, res, n50)
+    upd_ms_full, _ = time_update(policy, res, n_full, reps=2)
+
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     comm.all_reduce_max(t)
     dt_max = float(t.item())
@@ -189,7 +235,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "imagined env-steps/sec (ensemble rollout)",
+            "metric": "imagined env-steps/sec (ensemble rollout) + CPO update ms",
             "value": tot / dt_max,
             "unit": "imagined env-steps/s",
             "n_gpus": world,
@@ -211,9 +257,13 @@ def main():
                          "kernel": "ens_mlp_kernel<512,1,swish,prob>", "avg_launch_ms": avg_ms,
                          "launches": len(k_ms), "flop_per_branch_step": flop_per_row},
         }
+        out["cpo_update"] = {"unit": "ms", "n_50k": n50, "ms_50k": upd_ms_50k, "n_full": n_full,
+                             "ms_full": upd_ms_full, "optim_case": int(upd_info["OptimCase"]),
+                             "hvps": 22 if upd_info["OptimCase"] != 4 else 11, "per_rank": True}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, task, seconds=args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["cpu_baseline"]["cpo_update_ms_50k"] = cpu_update_baseline(w, res, n50)
         print(json.dumps(out), flush=True)
     comm.barrier()
 

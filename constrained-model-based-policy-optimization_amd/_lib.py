@@ -51,8 +51,10 @@ class RolloutStruct(C.Structure):
                                   "uncertainty_mode", "rank", "world")]
         + [("max_samples", C.c_int64), ("dkl_lim", C.c_double), ("gamma", C.c_double), ("lam", C.c_double),
            ("cost_gamma", C.c_double), ("cost_lam", C.c_double)]
+        + [(n, C.c_void_p) for n in ("alive_idx", "alive_idx_out", "iscal", "dscal")]
+        + [("use_host_budget", C.c_int32), ("host_rank_off", C.c_int32), ("host_excess", C.c_int64)]
         + [(n, C.c_void_p) for n in (
-            "alive_idx", "alive_idx_out", "iscal", "dscal", "g_counts", "alive", "fin_code", "len",
+            "alive", "fin_code", "len",
             "cur_obs", "next_obs", "act_t", "logp_t", "mu_t", "ls_t", "v_t", "vc_t", "v_n", "vc_n",
             "rew_t", "cost_t", "dkl_t", "epv_t", "term_t",
             "dkl_acc", "path_ret", "path_cost", "path_dyn_var",

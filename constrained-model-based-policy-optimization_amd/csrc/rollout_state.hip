@@ -147,19 +147,14 @@ __global__ __launch_bounds__(kScanThreads) void decide_kernel(const cmbpo_rollou
     long long excess = 0;
     int rank_off = 0;
     if (r.max_samples > 0) {
-      long long tot = (long long)r.dscal[CMBPO_D_TOTAL_SAMPLES], g_n = n, g_unc = n_unc;
-      if (r.g_counts) {
-        tot = 0; g_n = 0; g_unc = 0;
-        for (int q = 0; q < r.world; ++q) {
-          g_n += r.g_counts[4 * q + 0];
-          g_unc += r.g_counts[4 * q + 1];
-          tot += r.g_counts[4 * q + 2];
-          if (q < r.rank) rank_off += r.g_counts[4 * q + 0] - r.g_counts[4 * q + 1];
-        }
+      if (r.use_host_budget) {
+        excess = r.host_excess;
+        rank_off = r.host_rank_off;
+      } else {
+        // n = total + alive - too_uncertain; n = max(n - max_samples, 0)
+        excess = (long long)r.dscal[CMBPO_D_TOTAL_SAMPLES] + n - n_unc - (long long)r.max_samples;
+        if (excess < 0) excess = 0;
       }
-      // n = total + alive - too_uncertain; n = max(n - max_samples, 0)
-      excess = tot + g_n - g_unc - (long long)r.max_samples;
-      if (excess < 0) excess = 0;
     }
     s_excess = excess;
     s_rank_off = rank_off;

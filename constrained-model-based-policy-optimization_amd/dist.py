@@ -69,3 +69,20 @@ class Comm:
     def barrier(self):
         if self.world > 1:
             td.barrier()
+
+
+def budget_plan(rows, rank, max_samples):
+    """Cross-shard form of the budget rule of ``samplers/model_sampler.py:282-287``.
+
+    rows: int array [world, >=3] of per-rank {n_alive, n_too_uncertain, total_samples} in rank order
+    (ranks own contiguous blocks of global branch ids, so rank order == global index order).
+    Returns (excess, rank_off): `excess` surviving rows must be early-terminated, counted from global
+    index 0; `rank_off` of them precede this rank's first surviving row.
+    """
+    rows = [[int(v) for v in r] for r in rows]
+    g_alive = sum(r[0] for r in rows)
+    g_unc = sum(r[1] for r in rows)
+    g_total = sum(r[2] for r in rows)
+    excess = max(g_total + g_alive - g_unc - int(max_samples), 0)
+    rank_off = sum(r[0] - r[1] for r in rows[:rank])
+    return excess, rank_off

@@ -25,6 +25,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .dist import budget_plan
 
 EPS = 1e-8  # utilities/utils.py:19
 
@@ -196,10 +197,13 @@ class ModelSampler:
             rs.max_samples = int(max_samples) if max_samples else 0
             rs.dkl_lim = float(self.dkl_lim)
             rs.max_path_length = self._max_path_length
+            rs.use_host_budget = 0
             if self.comm is not None and self.comm.world > 1 and rs.max_samples > 0:
+                # budget rule across shards: gather {n_alive, n_unc, total}, rank the survivors globally
                 pool._call("cmbpo_rollout_count")
-                self._g_counts = self.comm.all_gather_i32(t["iscal"][8:12])
-                rs.g_counts = self._g_counts.data_ptr()
+                rows = self.comm.all_gather_i32(t["iscal"][8:12]).cpu().numpy()
+                excess, rank_off = budget_plan(rows, self.comm.rank, rs.max_samples)
+                rs.use_host_budget, rs.host_excess, rs.host_rank_off = 1, int(excess), int(rank_off)
             pool._call("cmbpo_rollout_decide")
             pool._call("cmbpo_rollout_finish", 0)
             pool._call("cmbpo_rollout_store")

@@ -89,7 +89,7 @@ class ModelBuffer:
         for name, _ in RolloutStruct._fields_:
             if name in self.t:
                 setattr(self.rs, name, self.t[name].data_ptr())
-        self.rs.g_counts = None
+        self.rs.use_host_budget = 0
 
     def swap(self, a, b):
         """Exchange two same-shaped state arrays (cur_obs <-> next_obs, v_t <-> v_n, ...)."""

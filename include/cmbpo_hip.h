@@ -154,7 +154,9 @@ typedef struct cmbpo_rollout {
   int32_t *alive_idx_out;   /* [B] list written by cmbpo_rollout_compact       */
   int32_t *iscal;           /* [32] see CMBPO_I_*                              */
   double *dscal;            /* [32] see CMBPO_D_*                              */
-  const int32_t *g_counts;  /* [world][4] gathered {n_alive,n_unc,..} or NULL  */
+  int32_t use_host_budget;  /* 1: take the two fields below instead of local counts */
+  int32_t host_rank_off;    /* surviving rows on lower ranks (global index order)   */
+  int64_t host_excess;      /* global rows to early-terminate this step              */
   uint8_t *alive;           /* [B] !terminated_paths_mask                      */
   uint8_t *fin_code;        /* [B] 0 keep, 1 finish w/ bootstrap, 2 terminal   */
   int32_t *len;             /* [B] populated entries of the branch             */
@@ -206,8 +208,9 @@ int cmbpo_rollout_reset(const cmbpo_rollout_t *r, void *stream);
  * (model_sampler.py:275-287) -> fin_code, counters. */
 int cmbpo_rollout_decide(const cmbpo_rollout_t *r, void *stream);
 /* Counting half of the above only: writes iscal[8..11] = {n_alive, n_unc,
- * total_samples, 0}, the row a sharded run all-gathers into g_counts before
- * cmbpo_rollout_decide (budget rule across shards). */
+ * total_samples, 0}, the row a sharded run all-gathers; the host turns the
+ * gathered rows into (host_excess, host_rank_off) for cmbpo_rollout_decide
+ * (budget rule across shards; dist.budget_plan). */
 int cmbpo_rollout_count(const cmbpo_rollout_t *r, void *stream);
 
 /* ModelBuffer.finish_path_multiple (modelbuffer.py:138-182) = reward + cost GAE

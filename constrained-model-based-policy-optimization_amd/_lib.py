@@ -99,6 +99,8 @@ SIGNATURES.update({
     "cmbpo_pi_loss_grad": (_i, [_p, _bp, _i, _p, _p, _p]),
     "cmbpo_pi_fvp": (_i, [_p, _bp, _p, _p, _p]),
     "cmbpo_pi_eval": (_i, [_p, _bp, _p, _p]),
+    "cmbpo_gae_segments": (_i, [_i] + [_p] * 8 + [C.c_double] * 4 + [_p] * 5),
+    "cmbpo_adv_normalize": (_i, [_i, _p, _p, _p, _p]),
 })
 
 _lib = None

@@ -295,6 +295,25 @@ int cmbpo_pi_fvp(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, const float *d_v,
 int cmbpo_pi_eval(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, double *d_sums,
                   void *stream);
 
+/* CPOBuffer.finish_path (buffers/cpobuffer.py:179-207) / any set of contiguous
+ * paths cut out of flat [N] arrays by d_offsets[n_paths+1]: reward + cost GAE
+ * (utilities/utils.py:184-188) with per-path bootstraps.  d_f64_mask (may be
+ * NULL) bit0/bit1: compute the reward/cost deltas in float64, which is what
+ * np.append does to the float32 buffers when the bootstrap is not float32
+ * (the np.zeros((1,)) of samplers/cpo_sampler.py:205-212). */
+int cmbpo_gae_segments(int n_paths, const int32_t *d_offsets, const float *d_rew,
+                       const float *d_val, const float *d_cost, const float *d_cval,
+                       const float *d_last_val, const float *d_last_cval,
+                       const uint8_t *d_f64_mask, double gamma, double lam,
+                       double cost_gamma, double cost_lam, float *d_adv,
+                       float *d_ret, float *d_cadv, float *d_cret, void *stream);
+
+/* CPOBuffer.get normalisation (buffers/cpobuffer.py:261-268): in place
+ * adv = (adv - mean) / (std + 1e-8), cadv -= mean(cadv), two-pass statistics of
+ * utilities/mpi_tools.py:71-87.  d_stats[16]: [0] n [1] adv_mean [2] adv_std
+ * [3] cadv_mean. */
+int cmbpo_adv_normalize(int n, float *d_adv, float *d_cadv, double *d_stats, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

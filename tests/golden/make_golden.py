@@ -367,6 +367,7 @@ def main():
     gen_gae_and_stats(HERE)
     gen_sampler_traces(HERE)
     gen_update_pi(HERE)
+    gen_cpobuffer(HERE)
     print("golden vectors written to", HERE)
 
 
@@ -487,8 +488,48 @@ def gen_update_pi(out):
     np.savez_compressed(os.path.join(out, "g7_update_pi.npz"), **data)
 
 
+def gen_cpobuffer(out):
+    """G8: the reference CPOBuffer on three real-env style paths (float32 and float64-zero bootstraps)."""
+    from buffers.cpobuffer import CPOBuffer
+    rng = np.random.default_rng(808)
+    D, A = 6, 2
+    buf = CPOBuffer(size=64, archive_size=256, observation_space=_Space(D), action_space=_Space(A))
+    buf.initialize({"mu": [A], "log_std": [A]}, gamma=0.99, lam=0.95, cost_gamma=0.97, cost_lam=0.5)
+    lengths = [7, 1, 12, 20]
+    boots = [("f32", "f32"), ("zero64", "f32"), ("f32", "f32"), ("zero64", "f32")]
+    n = sum(lengths)
+    data = dict(D=D, A=A, lengths=np.array(lengths), obs=rng.standard_normal((n, D)).astype(np.float32),
+                act=rng.standard_normal((n, A)).astype(np.float32),
+                rew=rng.standard_normal(n).astype(np.float32), val=rng.standard_normal(n).astype(np.float32),
+                cost=(rng.random(n) < 0.3).astype(np.float32), cval=rng.standard_normal(n).astype(np.float32),
+                logp=rng.standard_normal(n).astype(np.float32), mu=rng.standard_normal((n, A)).astype(np.float32),
+                log_std=np.full((n, A), -0.5, np.float32),
+                last_val=rng.standard_normal(len(lengths)).astype(np.float32),
+                last_cval=rng.standard_normal(len(lengths)).astype(np.float32),
+                zero_val=np.array([b[0] == "zero64" for b in boots]))
+    i = 0
+    for p, L in enumerate(lengths):
+        for _ in range(L):
+            buf.store(data["obs"][i], data["act"][i], data["obs"][i], data["rew"][i], data["val"][i], data["cost"][i],
+                      data["cval"][i], data["logp"][i], {"mu": data["mu"][i], "log_std": data["log_std"][i]}, False, 3)
+            i += 1
+        lv = np.zeros((1,)) if data["zero_val"][p] else data["last_val"][p:p + 1]
+        buf.finish_path(lv, data["last_cval"][p:p + 1])
+    res, diag = buf.get()
+    names = ["obs", "act", "adv", "cadv", "ret", "cret", "logp", "val", "cval", "cost", "log_std", "mu"]
+    for k, v in zip(names, res):
+        data["get_" + k] = v
+    data["poolr_ret_mean"], data["poolr_cret_mean"] = diag["poolr_ret_mean"], diag["poolr_cret_mean"]
+    data["arch_size"] = buf.arch_size
+    np.savez_compressed(os.path.join(out, "g8_cpobuffer.npz"), **data)
+    print("cpobuffer: samples", n, "archive", buf.arch_size)
+
+
 if __name__ == "__main__":
-    if "--update-only" in sys.argv:
+    if "--cpobuffer-only" in sys.argv:
+        install_stubs()
+        gen_cpobuffer(HERE)
+    elif "--update-only" in sys.argv:
         install_stubs()
         gen_update_pi(HERE)
     else:

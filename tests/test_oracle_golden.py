@@ -192,3 +192,29 @@ def test_oracle_graph_analytic_cross_checks():
     # (mu_old was rounded to float32, so a (mu_old - mu) * d2mu term of order 1e-7 remains)
     np.testing.assert_allclose(graph.fisher_vp(p64, v, 0.1), graph.hvp(p64, v, 0.1), rtol=1e-4, atol=1e-6)
     assert abs(kl(p64)) < 1e-6      # KL(p || p) = 0 (up to the 1e-8 in the denominator)
+
+
+def cpobuffer_oracle(g):
+    """buffers/cpobuffer.py:179-207,249-290 restated with the oracle's GAE / statistics."""
+    lengths = g["lengths"]
+    adv, ret, cadv, cret = [np.zeros(int(lengths.sum()), np.float32) for _ in range(4)]
+    lo = 0
+    for p, L in enumerate(lengths):
+        hi = lo + int(L)
+        lv = np.zeros((1,)) if g["zero_val"][p] else g["last_val"][p:p + 1]
+        a, r = refcpu.gae_rows(g["rew"][None, lo:hi], g["val"][None, lo:hi], lv[None, 0], 0.99, 0.95)
+        ca, cr = refcpu.gae_rows(g["cost"][None, lo:hi], g["cval"][None, lo:hi], g["last_cval"][None, p], 0.97, 0.5)
+        adv[lo:hi], ret[lo:hi], cadv[lo:hi], cret[lo:hi] = a[0], r[0], ca[0], cr[0]
+        lo = hi
+    m, s = refcpu.mpi_statistics_scalar(adv)
+    cm, _ = refcpu.mpi_statistics_scalar(cadv)
+    return (adv - m) / (s + 1e-8), cadv - cm, ret, cret
+
+
+def test_g8_cpobuffer_oracle_matches_reference():
+    g = _load("g8_cpobuffer")
+    adv, cadv, ret, cret = cpobuffer_oracle(g)
+    np.testing.assert_array_equal(ret, g["get_ret"])
+    np.testing.assert_array_equal(cret, g["get_cret"])
+    np.testing.assert_array_equal(adv.astype(np.float32), g["get_adv"])
+    np.testing.assert_array_equal(cadv.astype(np.float32), g["get_cadv"])

@@ -32,6 +32,8 @@ SIGNATURES = {
     "cmbpo_last_error": (C.c_char_p, []),
     "cmbpo_version": (_i, []),
     "cmbpo_set_block_rows": (_i, [_i]),
+    "cmbpo_set_stagger": (_i, [_i]),
+    "cmbpo_set_dispatch_mode": (_i, [_i]),
     "cmbpo_mlp_create": (_i, [C.POINTER(_p), _i, _i, _i, _i, _i, _i]),
     "cmbpo_mlp_destroy": (None, [_p]),
     "cmbpo_mlp_load": (_i, [_p] * 13),

@@ -29,6 +29,20 @@
 #include <string.h>
 #include <vector>
 
+#ifdef CMBPO_STAMPS
+// Diagnostic build only (tools/probe_stamps.py): per-workgroup phase timestamps of wave 0.
+static unsigned long long *g_stamps = nullptr;
+extern "C" void cmbpo_debug_set_stamps(unsigned long long *p) { g_stamps = p; }
+#define STAMP(k)                                                                                   \
+  do {                                                                                             \
+    if (p.stamps && threadIdx.x == 0)                                                              \
+      p.stamps[(size_t)stamp_item * 12 + (k)] =                                  \
+          ((k) >= 8 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime());                 \
+  } while (0)
+#else
+#define STAMP(k)
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -39,8 +53,8 @@ struct MlpKernelArgs {
   const f32x4 *wp0, *wp1, *wp2;
   size_t wp0_stride, wp1_stride, wp2_stride;  // per member, in float4
   const float *b0, *b1, *b2;                  // [E][HID],[E][HID],[E][o_pad]
-  const float *in_mu, *in_var;                // [in_dim] or nullptr
-  const float *out_mu, *out_var;              // [out_dim] or nullptr
+  const float *in_mu, *in_sig;                // [in_dim] or nullptr; sig = max(sqrt(var), 1e-2)
+  const float *out_mu, *out_sig, *out_lsig2;  // [out_dim] or nullptr; lsig2 = 2 log(sig)
   const float *log_std;                       // [out_dim] (policy head)
   int ensemble, e_chunk;
   int in_dim, in_pad;  // in_pad multiple of 8
@@ -60,22 +74,44 @@ struct MlpKernelArgs {
   float *out1;  // var  |              | logp
   float *out2;  //                     | mu
   float *out3;  //                     | log_std broadcast
+  unsigned long long *stamps;  // diagnostic builds only
+  int stagger_sleeps;          // s_sleep(127) repetitions for the second dispatch batch (0 = off)
+  int tiles, n_items, n_cu;    // persistent grid: items = member chunks x row tiles, member-major
+  int *work_counter;           // device counter for dynamic item claiming (nullptr: static striding)
 };
 
 template <int ACT>
 __device__ __forceinline__ float activate(float x) {
   if constexpr (ACT == CMBPO_ACT_SWISH) {
-    // x * sigmoid(x), models/pens/fc.py:19
-    return x / (1.0f + __expf(-x));
+    // x * sigmoid(x), models/pens/fc.py:19.  v_exp + v_rcp (1 ulp each) instead of an IEEE divide:
+    // the epilogue is VALU work that competes with the partner wave's MFMA issue.
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
   } else {
     return tanhf(x);
   }
 }
 
-// bias + activation, accumulator tile -> LDS image [n/4][BB] of float4.
+// Accumulators start from the bias (read from LDS as the same float4 groups the tile rows form), so the
+// epilogues have no bias add and no zero-initialising moves: VALU work next to a partner wave's fp32 MFMA
+// stream is the scarce resource of this kernel.
+template <int NT, int BT>
+__device__ __forceinline__ void init_acc_bias(f32x16 (&acc)[NT][BT], const float *bias, int n_base, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + n_base + t * 32 + 8 * q + 4 * h);
+#pragma unroll
+      for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[t][bt][4 * q + s] = bv[s];
+    }
+}
+
+// activation, accumulator tile -> LDS image [n/4][BB] of float4.
 template <int NT, int BT, int ACT>
 __device__ __forceinline__ void store_hidden(const f32x16 (&acc)[NT][BT],
-                                             const float *__restrict__ bias,
                                              int n_base, f32x4 *lds_out, int lane) {
   constexpr int BB = 32 * BT;
   const int j = lane & 31, h = lane >> 5;
@@ -85,15 +121,48 @@ __device__ __forceinline__ void store_hidden(const f32x16 (&acc)[NT][BT],
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = n0 + 8 * q + 4 * h;
-      const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + n);
 #pragma unroll
       for (int bt = 0; bt < BT; ++bt) {
         f32x4 v;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) v[s] = activate<ACT>(acc[t][bt][4 * q + s] + bv[s]);
+        for (int s = 0; s < 4; ++s) v[s] = activate<ACT>(acc[t][bt][4 * q + s]);
         lds_out[(n >> 2) * BB + bt * 32 + j] = v;
       }
     }
+  }
+}
+
+// activation in place: the accumulator tile becomes the B operand of the output layer.
+template <int NT, int BT, int ACT>
+__device__ __forceinline__ void activate_regs(f32x16 (&acc)[NT][BT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][bt][r] = activate<ACT>(acc[t][bt][r]);
+}
+
+// Output-layer slice straight from registers.  The accumulator rows a wave owns after a hidden layer
+// (n = n_base + 32 t + (r & 3) + 8 (r >> 2) + 4 h) are exactly the k indices the packed A layout assigns to
+// k-group g = n_base / 8 + 4 t + (r >> 2), element s = r & 3 of lane-half h -- so hreg[t][bt][r] IS the
+// B fragment of MFMA step (g, s) and the output layer's K split over the waves needs no LDS round trip.
+template <int NT, int BT>
+__device__ __forceinline__ void mfma_from_regs(const f32x4 *__restrict__ wp, int g_base, const f32x16 (&hreg)[NT][BT],
+                                               int lane, f32x16 (&out)[BT]) {
+  f32x4 a_cur = wp[(size_t)g_base * 64 + lane], a_nxt;
+#pragma unroll
+  for (int i = 0; i < NT * 4; ++i) {
+    const int t = i >> 2, q = i & 3;
+    const int inext = (i + 1 < NT * 4) ? i + 1 : i;
+    a_nxt = wp[(size_t)(g_base + inext) * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int bt = 0; bt < BT; ++bt)
+        out[bt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], hreg[t][bt][4 * q + s], out[bt], 0, 0, 0);
+    a_cur = a_nxt;
   }
 }
 
@@ -111,105 +180,165 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
   f32x4 *hbuf = smem;
   float *red = reinterpret_cast<float *>(smem);  // aliases hbuf (used after it is dead)
   f32x4 *xbuf = smem + (hbuf_f4 > red_f4 ? hbuf_f4 : red_f4);
-  int *rows = reinterpret_cast<int *>(xbuf + p.in_pad / 4 * BB);
+  float *bias_l = reinterpret_cast<float *>(xbuf + p.in_pad / 4 * BB);   // [HID | HID | o_tiles*32] of one member
+  float *oconst = bias_l + 2 * HID + p.o_tiles * 32;   // [sig | 2 log sig | mu] x out_dim (output scaler)
+  int *rows = reinterpret_cast<int *>(oconst + 3 * p.out_dim);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_rows = p.n_rows_dev ? *p.n_rows_dev : p.n_rows;
-  const int row0 = blockIdx.x * BB;
-  if (row0 >= n_rows) return;
+  // Stagger: the workgroups that share a CU run the same program and would otherwise stay in lockstep (all in
+  // their latency-bound prologue / epilogue at once, then all fighting for the MFMA pipe).  The dispatcher
+  // deals the first n_cu workgroups one per CU and the next ones on top of them, so delaying that second
+  // batch once by about half an item puts the pairs in anti-phase.  Placement is only a speed assumption: a
+  // wrong guess costs the delay, never correctness.
+  if (p.stagger_sleeps > 0 && (int)blockIdx.x >= p.n_cu && (int)blockIdx.x < 2 * p.n_cu) {
+    for (int i = 0; i < p.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  if constexpr (HEAD == CMBPO_HEAD_PROB || HEAD == CMBPO_HEAD_DETMEAN) {
+    // output scaler constants, once per workgroup (models/pens/utils.py:167,187)
+    if (tid < p.out_dim) {
+      oconst[tid] = p.out_mu ? p.out_sig[tid] : 1.0f;
+      oconst[p.out_dim + tid] = p.out_mu ? p.out_lsig2[tid] : 0.0f;
+      oconst[2 * p.out_dim + tid] = p.out_mu ? p.out_mu[tid] : 0.0f;
+    }
+  }
+  // Persistent workgroups: the grid is sized to what is co-resident (2 per CU for the 512-wide ensemble) and
+  // each workgroup strides over the (member chunk, row tile) items in member-major order, so the hardware
+  // dispatcher never has to back-fill a CU (measured: 20-36 us gaps per slot on half of the CUs with one
+  // workgroup per item) and concurrently running workgroups share one member's weights in L2.
+  __shared__ int s_item;
+  for (int item = blockIdx.x;;) {
+  if (p.work_counter) {
+    // dynamic claiming: one returning device-scope atomic per item (MI355X_MICROARCH "dequeue": 0.3-1 us)
+    if (tid == 0) s_item = atomicAdd(p.work_counter, 1);
+    __syncthreads();
+    item = s_item;
+  }
+  if (item >= p.n_items) break;
+  const int chunk = item / p.tiles;
+  const int row0 = (item - chunk * p.tiles) * BB;
+  if (row0 >= n_rows) {
+    if (!p.work_counter) item += gridDim.x;
+    else __syncthreads();
+    continue;
+  }
+#ifdef CMBPO_STAMPS
+  const int stamp_item = item;
+#endif
+  STAMP(0);
+  STAMP(8);
+#ifdef CMBPO_STAMPS
+  if (p.stamps && threadIdx.x == 0) {
+    p.stamps[(size_t)stamp_item * 12 + 10] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+    p.stamps[(size_t)stamp_item * 12 + 11] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+  }
+#endif
 
   // ---- stage the (scaled) input tile: xT[k][b], k = [obs | act] ------------
-  if (tid < BB) {
-    const int r = row0 + tid;
-    rows[tid] = (r < n_rows) ? (p.row_idx ? p.row_idx[r] : r) : -1;
-  }
+  // 8 threads per branch row; every thread issues all of its (independent) global loads before it
+  // touches LDS, so the prologue pays the memory latency once instead of once per element.
   {
     float *xf = reinterpret_cast<float *>(xbuf);
-    // zero the k padding [in_dim, in_pad)
-    const int npad = (p.in_pad - p.in_dim) * BB;
-    for (int i = tid; i < npad; i += kThreads) {
-      const int b = i % BB, k = p.in_dim + i / BB;
-      xf[((k >> 2) * BB + b) * 4 + (k & 3)] = 0.0f;
-    }
-  }
-  __syncthreads();
-  {
-    float *xf = reinterpret_cast<float *>(xbuf);
-    const int n_in = p.in_dim * BB;
-    for (int i = tid; i < n_in; i += kThreads) {
-      const int b = i / p.in_dim, k = i - b * p.in_dim;
-      const int r = rows[b];
-      float v = 0.0f;
-      if (r >= 0) {
-        v = (k < p.obs_dim) ? p.obs[(size_t)r * p.obs_dim + k]
-                            : p.act[(size_t)r * p.act_dim + (k - p.obs_dim)];
-        if (p.in_mu) {
-          // TensorStandardScaler.transform, models/pens/utils.py:156
-          const float sig = fmaxf(sqrtf(p.in_var[k]), 1e-2f);
-          v = (v - p.in_mu[k]) / sig;
+    const int c = tid & 7;
+#pragma unroll
+    for (int rb = 0; rb < BT; ++rb) {
+      const int b = (tid >> 3) + 32 * rb;
+      int r = row0 + b;
+      r = (r < n_rows) ? (p.row_idx ? p.row_idx[r] : r) : -1;
+      if (c == 0) rows[b] = r;
+      for (int k0 = 0; k0 < p.in_pad; k0 += 64) {
+        float v[8], mu[8], sig[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = k0 + c + 8 * u;
+          v[u] = 0.0f; mu[u] = 0.0f; sig[u] = 1.0f;
+          if (k < p.in_dim) {
+            if (r >= 0)
+              v[u] = (k < p.obs_dim) ? p.obs[(size_t)r * p.obs_dim + k] : p.act[(size_t)r * p.act_dim + (k - p.obs_dim)];
+            if (p.in_mu) { mu[u] = p.in_mu[k]; sig[u] = p.in_sig[k]; }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = k0 + c + 8 * u;
+          if (k < p.in_pad) {
+            float x = v[u];
+            if (p.in_mu && k < p.in_dim && r >= 0) {
+              // TensorStandardScaler.transform, models/pens/utils.py:156 (sig precomputed at load time)
+              x = (x - mu[u]) / sig[u];
+            }
+            xf[((k >> 2) * BB + b) * 4 + (k & 3)] = x;   // k >= in_dim: zero padding
+          }
         }
       }
-      xf[((k >> 2) * BB + b) * 4 + (k & 3)] = v;
     }
   }
-  __syncthreads();
 
-  const int e_begin = blockIdx.y * p.e_chunk;
+  const int e_begin = chunk * p.e_chunk;
   const int e_end = min(p.ensemble, e_begin + p.e_chunk);
   float member_sum = 0.0f;  // HEAD_DETMEAN: running sum over members
 
   for (int e = e_begin; e < e_end; ++e) {
     const int kg0 = p.in_pad / 8;
+    const int o_pad = p.o_tiles * 32;
+    // biases of this member -> LDS (read back as float4 in the epilogues; a global load there would
+    // expose its latency 16 times per layer)
+    STAMP(1);
+    if (e > e_begin) __syncthreads();   // previous member's epilogue still reads bias_l / red (= hbuf)
+    {
+      constexpr int kMaxB = (2 * HID + 128 + kThreads - 1) / kThreads;
+      float tmp[kMaxB];
+#pragma unroll
+      for (int u = 0; u < kMaxB; ++u) {
+        const int i = tid + u * kThreads;
+        tmp[u] = 0.0f;
+        if (i < 2 * HID + o_pad)
+          tmp[u] = (i < HID) ? p.b0[(size_t)e * HID + i]
+                             : (i < 2 * HID) ? p.b1[(size_t)e * HID + (i - HID)] : p.b2[(size_t)e * o_pad + (i - 2 * HID)];
+      }
+#pragma unroll
+      for (int u = 0; u < kMaxB; ++u) {
+        const int i = tid + u * kThreads;
+        if (i < 2 * HID + o_pad) bias_l[i] = tmp[u];
+      }
+    }
+    __syncthreads();   // x tile (first member) and this member's biases are in LDS
     // ---- layer 0: in -> HID ------------------------------------------------
     {
       f32x16 acc[NT][BT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int bt = 0; bt < BT; ++bt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[t][bt][r] = 0.0f;
+      init_acc_bias<NT, BT>(acc, bias_l, wave * NT * 32, lane);
       const f32x4 *wp = p.wp0 + e * p.wp0_stride + (size_t)(wave * NT) * kg0 * 64;
       mfma_layer<NT, BT>(wp, (size_t)kg0 * 64, 0, kg0, xbuf, lane, acc);
-      // hbuf may still be read (as `red`) by the previous member's epilogue
-      __syncthreads();
-      store_hidden<NT, BT, ACT>(acc, p.b0 + (size_t)e * HID, wave * NT * 32, hbuf, lane);
+      STAMP(2);
+      store_hidden<NT, BT, ACT>(acc, wave * NT * 32, hbuf, lane);
     }
     __syncthreads();
-    // ---- layer 1: HID -> HID -----------------------------------------------
+    STAMP(3);
+    // ---- layer 1: HID -> HID, then layer 2: HID -> o_width from registers --------------------
     {
       f32x16 acc[NT][BT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int bt = 0; bt < BT; ++bt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[t][bt][r] = 0.0f;
+      init_acc_bias<NT, BT>(acc, bias_l + HID, wave * NT * 32, lane);
       const f32x4 *wp = p.wp1 + e * p.wp1_stride + (size_t)(wave * NT) * KG_H * 64;
       mfma_layer<NT, BT>(wp, (size_t)KG_H * 64, 0, KG_H, hbuf, lane, acc);
-      __syncthreads();  // every wave has finished reading h1
-      store_hidden<NT, BT, ACT>(acc, p.b1 + (size_t)e * HID, wave * NT * 32, hbuf, lane);
-    }
-    __syncthreads();
-    // ---- layer 2: HID -> o_width, K split over the 4 waves -------------------
-    {
-      constexpr int KGQ = KG_H / kWaves;
+      STAMP(4);
+      activate_regs<NT, BT, ACT>(acc);   // h2 slice of this wave
+      // K of the output layer is split over the waves: wave w contributes k in [128 w, 128 w + 128) for
+      // HID = 512 ([32 w, 32 w + 32) for 128) -- its own h2 slice
       f32x16 part[4][BT];  // o_tiles <= 4, statically indexed below
 #pragma unroll
       for (int ot = 0; ot < 4; ++ot) {
         if (ot < p.o_tiles) {
-          f32x16 acc[1][BT];
 #pragma unroll
           for (int bt = 0; bt < BT; ++bt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][bt][r] = 0.0f;
-          const f32x4 *wp = p.wp2 + e * p.wp2_stride + (size_t)ot * KG_H * 64;
-          mfma_layer<1, BT>(wp, 0, wave * KGQ, (wave + 1) * KGQ, hbuf, lane, acc);
-#pragma unroll
-          for (int bt = 0; bt < BT; ++bt) part[ot][bt] = acc[0][bt];
+            for (int r = 0; r < 16; ++r) part[ot][bt][r] = 0.0f;
+          const f32x4 *wp2 = p.wp2 + e * p.wp2_stride + (size_t)ot * KG_H * 64;
+          mfma_from_regs<NT, BT>(wp2, wave * NT * 4, acc, lane, part[ot]);
         }
       }
-      __syncthreads();  // h2 dead: hbuf becomes the reduction image
+      STAMP(5);
+      __syncthreads();  // every wave has finished reading h1: hbuf becomes the reduction image
+      STAMP(6);
       const int j = lane & 31, h = lane >> 5;
 #pragma unroll
       for (int ot = 0; ot < 4; ++ot) {
@@ -233,36 +362,28 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
       v += red[(1 * o_ld + n) * RED_LD + b];
       v += red[(2 * o_ld + n) * RED_LD + b];
       v += red[(3 * o_ld + n) * RED_LD + b];
-      return v + p.b2[(size_t)e * o_ld + n];
+      return v + bias_l[2 * HID + n];
     };
     if constexpr (HEAD == CMBPO_HEAD_PROB) {
       // mean = sig*o + mu ; var = exp(2*log(sig) + o'), models/pens/pe.py:815-835
       const int out = p.out_dim;
+      const float inv_out = 1.0f / (float)out;
       for (int i = tid; i < BB * out; i += kThreads) {
-        const int b = i / out, n = i - b * out;
+        const int b = (int)(((float)i + 0.5f) * inv_out);   // exact for i < 2^16, out <= 128
+        const int n = i - b * out;
         const int r = rows[b];
         if (r < 0) continue;
-        float m = reduced(b, n);
-        float lv = reduced(b, out + n);
-        if (p.out_mu) {
-          const float sig = fmaxf(sqrtf(p.out_var[n]), 1e-2f);
-          m = sig * m + p.out_mu[n];
-          lv = 2.0f * logf(sig) + lv;
-        }
+        const float m = oconst[n] * reduced(b, n) + oconst[2 * out + n];
+        const float lv = oconst[out + n] + reduced(b, out + n);
         const size_t o = ((size_t)e * p.ld_rows + r) * out + n;
         p.out0[o] = m;
-        p.out1[o] = expf(lv);
+        p.out1[o] = __expf(lv);
       }
     } else if constexpr (HEAD == CMBPO_HEAD_DETMEAN) {
       const int out = p.out_dim;
       if (tid < BB * out) {
         const int b = tid / out, n = tid - b * out;
-        float m = reduced(b, n);
-        if (p.out_mu) {
-          const float sig = fmaxf(sqrtf(p.out_var[n]), 1e-2f);
-          m = sig * m + p.out_mu[n];
-        }
-        member_sum += m;
+        member_sum += oconst[n] * reduced(b, n) + oconst[2 * out + n];
       }
     } else {  // CMBPO_HEAD_GAUSS_PI
       const int A = p.out_dim;
@@ -302,6 +423,11 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
       if (r >= 0) p.out0[(size_t)r * out + n] = member_sum / (float)p.ensemble;
     }
   }
+  STAMP(7);
+  STAMP(9);
+  __syncthreads();   // the next item re-uses xbuf / rows / red / s_item
+  if (!p.work_counter) item += gridDim.x;
+  }  // persistent item loop
 }
 
 // Host-side packing: W[K][N] row-major -> [n-tile][k-group][lane][4].
@@ -329,7 +455,7 @@ struct cmbpo_mlp {
   size_t blob_floats;
   // offsets (in floats) into the blob
   size_t off_wp0, off_wp1, off_wp2, off_b0, off_b1, off_b2;
-  size_t off_in_mu, off_in_var, off_out_mu, off_out_var, off_log_std;
+  size_t off_in_mu, off_in_var, off_out_mu, off_out_var, off_out_lsig2, off_log_std;   // *_var hold sigma
   std::vector<float> h_blob;
 };
 
@@ -367,7 +493,7 @@ extern "C" int cmbpo_mlp_create(cmbpo_mlp_t **out, int ensemble, int in_dim, int
   m->off_b1 = take((size_t)E * H);
   m->off_b2 = take((size_t)E * m->o_tiles * 32);
   m->off_in_mu = take(in_dim); m->off_in_var = take(in_dim);
-  m->off_out_mu = take(m->out_dim); m->off_out_var = take(m->out_dim);
+  m->off_out_mu = take(m->out_dim); m->off_out_var = take(m->out_dim); m->off_out_lsig2 = take(m->out_dim);
   m->off_log_std = take(m->out_dim);
   m->blob_floats = off;
   m->d_blob = nullptr;
@@ -414,13 +540,19 @@ extern "C" int cmbpo_mlp_load(cmbpo_mlp_t *m, const float *h_w0, const float *h_
   }
   m->has_in_scaler = h_in_mu != nullptr;
   m->has_out_scaler = h_out_mu != nullptr;
+  // scaler sigmas in float32, max(sqrt(var), 1e-2) (models/pens/utils.py:156,167,187); sqrtf is correctly
+  // rounded on the host, the device only divides / multiplies by them
   if (h_in_mu) {
     memcpy(hb + m->off_in_mu, h_in_mu, I * sizeof(float));
-    memcpy(hb + m->off_in_var, h_in_var, I * sizeof(float));
+    for (int k = 0; k < I; ++k) hb[m->off_in_var + k] = fmaxf(sqrtf(h_in_var[k]), 1e-2f);
   }
   if (h_out_mu) {
     memcpy(hb + m->off_out_mu, h_out_mu, m->out_dim * sizeof(float));
-    memcpy(hb + m->off_out_var, h_out_var, m->out_dim * sizeof(float));
+    for (int k = 0; k < m->out_dim; ++k) {
+      const float sig = fmaxf(sqrtf(h_out_var[k]), 1e-2f);
+      hb[m->off_out_var + k] = sig;
+      hb[m->off_out_lsig2 + k] = 2.0f * logf(sig);
+    }
   }
   if (h_log_std) memcpy(hb + m->off_log_std, h_log_std, m->out_dim * sizeof(float));
   // h_blob stays alive in the handle until the next load, so the async copy is safe.
@@ -432,21 +564,59 @@ extern "C" int cmbpo_mlp_load(cmbpo_mlp_t *m, const float *h_w0, const float *h_
 
 namespace {
 
-template <int HID, int BT, int ACT, int HEAD>
-int launch_one(const MlpKernelArgs &a, int tiles, int grid_y, size_t lds, hipStream_t s) {
-  auto kern = ens_mlp_kernel<HID, BT, ACT, HEAD>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+int g_dispatch_mode = 0;   // 0: one workgroup per item (hardware dispatch), 1: persistent static, 2: persistent dynamic
+int *g_work_counter = nullptr;
+
+int device_cu_count() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles, grid_y), dim3(kThreads), lds, s, a);
+  return n_cu;
+}
+
+template <int HID, int BT, int ACT, int HEAD>
+int launch_one(MlpKernelArgs &a, int tiles, int chunks, size_t lds, hipStream_t s) {
+  auto kern = ens_mlp_kernel<HID, BT, ACT, HEAD>;
+  static size_t attr_bytes = 0;   // the kernel also has a few bytes of static LDS: ask for what is needed
+  static size_t occ_lds = ~(size_t)0;
+  static int per_cu = 1;
+  if (lds > attr_bytes) {
+    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_bytes = lds;
+  }
+  if (occ_lds != lds) {   // co-resident workgroups per CU for this LDS footprint
+    int nb = 0;
+    CMBPO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kThreads, lds));
+    per_cu = nb < 1 ? 1 : (nb > 4 ? 4 : nb);
+    occ_lds = lds;
+  }
+  a.tiles = tiles;
+  a.n_items = tiles * chunks;
+  a.n_cu = device_cu_count();
+  const int resident = per_cu * a.n_cu;
+  int grid = a.n_items < resident ? a.n_items : resident;
+  a.work_counter = nullptr;
+  if (g_dispatch_mode == 0) {
+    grid = a.n_items;                       // every workgroup runs exactly one item
+  } else if (g_dispatch_mode == 2) {
+    if (!g_work_counter) CMBPO_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&g_work_counter), sizeof(int)));
+    CMBPO_HIP_CHECK(hipMemsetAsync(g_work_counter, 0, sizeof(int), s));
+    a.work_counter = g_work_counter;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, s, a);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }
 
 int g_block_rows = 32;  // 32 (2 workgroups / CU) or 64 (1 workgroup / CU)
+int g_stagger = 10;     // x s_sleep(127) (~8k cycles each) for the second dispatch batch
+int g_lds_pad = 0;      // diagnostic: extra dynamic LDS bytes (forces one workgroup per CU)
 
 int launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
   const float *blob = m->d_blob;
@@ -459,10 +629,15 @@ int launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
   a.wp2_stride = (size_t)m->o_tiles * (H / 8) * 64;
   a.b0 = blob + m->off_b0; a.b1 = blob + m->off_b1; a.b2 = blob + m->off_b2;
   a.in_mu = m->has_in_scaler ? blob + m->off_in_mu : nullptr;
-  a.in_var = m->has_in_scaler ? blob + m->off_in_var : nullptr;
+  a.in_sig = m->has_in_scaler ? blob + m->off_in_var : nullptr;
   a.out_mu = m->has_out_scaler ? blob + m->off_out_mu : nullptr;
-  a.out_var = m->has_out_scaler ? blob + m->off_out_var : nullptr;
+  a.out_sig = m->has_out_scaler ? blob + m->off_out_var : nullptr;
+  a.out_lsig2 = m->has_out_scaler ? blob + m->off_out_lsig2 : nullptr;
   a.log_std = blob + m->off_log_std;
+#ifdef CMBPO_STAMPS
+  a.stamps = g_stamps;
+#endif
+  a.stagger_sleeps = (H == 512) ? g_stagger : 0;
   a.ensemble = E;
   a.e_chunk = (m->head == CMBPO_HEAD_PROB) ? 1 : E;
   a.in_dim = m->in_dim; a.in_pad = m->in_pad;
@@ -475,11 +650,11 @@ int launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
   const int grid_y = cmbpo_ceil_div(E, a.e_chunk);
   const size_t hbuf = (size_t)H * BB * 4;
   const size_t red = ((size_t)kWaves * m->o_tiles * 32 * (BB + 1) * 4 + 15) / 16 * 16;
-  const size_t lds = (hbuf > red ? hbuf : red) + (size_t)m->in_pad * BB * 4 + BB * 4;
-  CMBPO_REQUIRE(lds <= 160 * 1024, "ens_mlp: LDS budget exceeded (%zu B)", lds);
+  const size_t lds = (hbuf > red ? hbuf : red) + (size_t)m->in_pad * BB * 4 + (2 * H + m->o_tiles * 32 + 3 * m->out_dim) * 4 + BB * 4;
+  CMBPO_REQUIRE(lds + g_lds_pad <= 160 * 1024, "ens_mlp: LDS budget exceeded (%zu B)", lds + g_lds_pad);
 
 #define CMBPO_LAUNCH(HID_, BT_, ACT_, HEAD_) \
-  return launch_one<HID_, BT_, ACT_, HEAD_>(a, tiles, grid_y, lds, s)
+  return launch_one<HID_, BT_, ACT_, HEAD_>(a, tiles, grid_y, lds + g_lds_pad, s)
   if (m->head == CMBPO_HEAD_PROB && m->act == CMBPO_ACT_SWISH) {
     if (H == 512 && BT == 1) CMBPO_LAUNCH(512, 1, CMBPO_ACT_SWISH, CMBPO_HEAD_PROB);
     if (H == 512 && BT == 2) CMBPO_LAUNCH(512, 2, CMBPO_ACT_SWISH, CMBPO_HEAD_PROB);
@@ -497,6 +672,23 @@ int launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int cmbpo_set_dispatch_mode(int mode) {
+  CMBPO_REQUIRE(mode >= 0 && mode <= 2, "cmbpo_set_dispatch_mode: 0 (per-item), 1 (persistent static), 2 (persistent dynamic)");
+  g_dispatch_mode = mode;
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_debug_set_lds_pad(int bytes) {
+  g_lds_pad = bytes;
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_set_stagger(int sleeps) {
+  CMBPO_REQUIRE(sleeps >= 0 && sleeps <= 64, "cmbpo_set_stagger: 0..64");
+  g_stagger = sleeps;
+  return CMBPO_OK;
+}
 
 extern "C" int cmbpo_set_block_rows(int rows) {
   CMBPO_REQUIRE(rows == 32 || rows == 64, "cmbpo_set_block_rows: 32 or 64");

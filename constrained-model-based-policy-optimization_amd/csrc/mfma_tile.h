@@ -12,35 +12,55 @@
 // [g0, g1).  wp points at this wave's first n-tile for k-group 0; consecutive
 // n-tiles are `nt_stride` float4 apart.  lds_in is the [K/4][BB] float4 image.
 template <int NT, int BT>
+__device__ __forceinline__ void mfma_block(const f32x4 (&a)[NT], const f32x4 (&b)[BT], f32x16 (&acc)[NT][BT]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int bt = 0; bt < BT; ++bt)
+        acc[t][bt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s], b[bt][s], acc[t][bt], 0, 0, 0);
+}
+
+template <int NT, int BT>
 __device__ __forceinline__ void mfma_layer(const f32x4 *__restrict__ wp,
                                            size_t nt_stride, int g0, int g1,
                                            const f32x4 *lds_in, int lane,
                                            f32x16 (&acc)[NT][BT]) {
   constexpr int BB = 32 * BT;
   const int j = lane & 31, h = lane >> 5;
-  f32x4 a_cur[NT], a_nxt[NT];
+  // Software pipeline, one k-group deep, ping-pong register sets (no copies): the A fragments (global / L2)
+  // and B fragments (LDS) of group g + 1 are requested before the 4*NT*BT MFMAs of group g are issued and
+  // are first needed a full MFMA block (>= 1024 cycles) later.  The sched_barrier after each request pins
+  // it above the block: left alone, hipcc sinks the loads next to their first use and the L2 latency is
+  // exposed once per k-group; everything else (address arithmetic, loop control) may interleave freely.
+  f32x4 a0[NT], a1[NT], b0[BT], b1[BT];
+  const f32x4 *lds_lane = lds_in + h * BB + j;
+  auto request = [&](int g, f32x4 (&a)[NT], f32x4 (&b)[BT]) {
+    const f32x4 *wg = wp + (size_t)g * 64;          // wave-uniform: scalar pointer arithmetic
 #pragma unroll
-  for (int t = 0; t < NT; ++t) a_cur[t] = wp[t * nt_stride + (size_t)g0 * 64 + lane];
-  for (int g = g0; g < g1; ++g) {
-    const int gn = (g + 1 < g1) ? g + 1 : g;
+    for (int t = 0; t < NT; ++t) a[t] = (wg + t * nt_stride)[lane];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) a_nxt[t] = wp[t * nt_stride + (size_t)gn * 64 + lane];
-    f32x4 b[BT];
-#pragma unroll
-    for (int bt = 0; bt < BT; ++bt) b[bt] = lds_in[(2 * g + h) * BB + bt * 32 + j];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int bt = 0; bt < BT; ++bt) {
-          acc[t][bt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t][s], b[bt][s],
-                                                            acc[t][bt], 0, 0, 0);
-        }
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) a_cur[t] = a_nxt[t];
+    for (int bt = 0; bt < BT; ++bt) b[bt] = lds_lane[2 * g * BB + bt * 32];
+  };
+  request(g0, a0, b0);
+  int g = g0;
+#pragma unroll 1
+  for (; g + 1 < g1; g += 2) {
+#ifdef CMBPO_DIAG_NOLOAD   // diagnostic: same MFMA stream, operands never refreshed
+    if (g == g0) request(g + 1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block<NT, BT>(a0, b0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block<NT, BT>(a1, b1, acc);
+#else
+    request(g + 1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block<NT, BT>(a0, b0, acc);
+    request((g + 2 < g1) ? g + 2 : g + 1, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block<NT, BT>(a1, b1, acc);
+#endif
   }
+  if (g < g1) mfma_block<NT, BT>(a0, b0, acc);
 }
-

@@ -54,6 +54,13 @@ int cmbpo_version(void);
 /* Tuning knob (no reference counterpart): branches per workgroup of the 512-wide
  * ensemble kernel, 32 (two workgroups per CU) or 64 (one, half the L2 weight traffic). */
 int cmbpo_set_block_rows(int rows);
+/* Tuning knob: start-up stagger of the second dispatch batch of the 512-wide ensemble kernel, in units
+ * of s_sleep(127) (~8k cycles); 0 disables it. */
+int cmbpo_set_stagger(int sleeps);
+/* Tuning knob: how the ensemble kernels walk their (member, row-tile) items: 0 = one workgroup per item
+ * (hardware dispatch), 1 = persistent workgroups with static striding, 2 = persistent with a device work
+ * counter. */
+int cmbpo_set_dispatch_mode(int mode);
 
 /* ------------------------------------------------------------------------ *
  * Ensemble MLP handle: a 3-layer (in -> H -> H -> O) ensemble of E members.

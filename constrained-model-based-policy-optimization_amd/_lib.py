@@ -67,7 +67,7 @@ class RolloutStruct(C.Structure):
 
 
 # iscal / dscal slots (CMBPO_I_* / CMBPO_D_* in the header)
-I_N_ALIVE, I_N_UNC, I_N_FIN_PRE, I_N_STORED, I_N_ALIVE_OUT, I_SIZE = 0, 1, 2, 3, 4, 5
+I_N_ALIVE, I_N_UNC, I_N_FIN_PRE, I_N_STORED, I_N_ALIVE_OUT, I_SIZE, I_N_FIN_POST = 0, 1, 2, 3, 4, 5, 6
 (D_TOTAL_SAMPLES, D_TOTAL_COST, D_TOTAL_REW, D_TOTAL_VS, D_TOTAL_CVS, D_TOTAL_DKL, D_TOTAL_DYN_EP_VAR,
  D_MAX_DKL, D_MAX_PATH_RETURN, D_DKL_SUM_T, D_STEP_MAX_DKL, D_SUM_PATH_RET, D_SUM_PATH_COST) = range(13)
 

@@ -118,75 +118,81 @@ __device__ __forceinline__ bool too_uncertain(const cmbpo_rollout_t &r, int b) {
   return r.uncertainty_mode && (r.dkl_acc[b] + (double)r.dkl_t[b] >= r.dkl_lim);
 }
 
-__global__ __launch_bounds__(kScanThreads) void decide_kernel(const cmbpo_rollout_t r, int count_only) {
-  __shared__ int sm_i[17];
+// pass 1 (grid): uncertainty flags -> fin_code, counts of this step
+__global__ __launch_bounds__(256) void decide_flags_kernel(const cmbpo_rollout_t r) {
   __shared__ double sm_d[16];
-  __shared__ long long s_excess;
-  __shared__ int s_rank_off;
-  const int tid = threadIdx.x;
   const int n = r.iscal[CMBPO_I_N_ALIVE];
-
   int cnt = 0;
   double dsum = 0.0;
-  for (int i = tid; i < n; i += kScanThreads) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int b = r.alive_idx[i];
-    cnt += too_uncertain(r, b) ? 1 : 0;
+    const bool u = too_uncertain(r, b);
+    r.fin_code[b] = u ? 1 : 0;
+    cnt += u ? 1 : 0;
     dsum += (double)r.dkl_t[b];
   }
-  const double n_unc_d = block_sum((double)cnt, sm_d);
-  const double dkl_sum = block_sum(dsum, sm_d);
+  const double c = block_sum((double)cnt, sm_d);
+  const double d = block_sum(dsum, sm_d);
+  if (threadIdx.x == 0) {
+    if (c > 0.0) atomicAdd(&r.iscal[CMBPO_I_N_UNC], (int)c);
+    atomicAdd(&r.dscal[CMBPO_D_DKL_SUM_T], d);
+  }
+}
+
+__global__ void decide_clear_kernel(const cmbpo_rollout_t r) {
+  r.iscal[CMBPO_I_N_UNC] = 0;
+  r.iscal[CMBPO_I_N_STORED] = 0;
+  r.iscal[CMBPO_I_N_FIN_POST] = 0;
+  r.dscal[CMBPO_D_DKL_SUM_T] = 0.0;
+}
+
+// pass 2 (one workgroup): budget rule -- the first `excess` surviving rows in index order are finished too.
+// Exits at once when the budget is not exceeded (every step but the last one or two of a rollout).
+__global__ __launch_bounds__(kScanThreads) void decide_budget_kernel(const cmbpo_rollout_t r, int count_only) {
+  __shared__ int sm_i[17];
+  __shared__ double sm_d[16];
+  const int tid = threadIdx.x;
+  const int n = r.iscal[CMBPO_I_N_ALIVE];
+  const int n_unc = r.iscal[CMBPO_I_N_UNC];
   if (tid == 0) {
-    const int n_unc = (int)n_unc_d;
-    r.iscal[CMBPO_I_N_UNC] = n_unc;
-    r.dscal[CMBPO_D_DKL_SUM_T] = dkl_sum;
     // the row other shards gather: {n_alive, n_unc, total_samples, 0}
     r.iscal[8] = n;
     r.iscal[9] = n_unc;
     r.iscal[10] = (int)r.dscal[CMBPO_D_TOTAL_SAMPLES];
     r.iscal[11] = 0;
-    long long excess = 0;
-    int rank_off = 0;
-    if (r.max_samples > 0) {
-      if (r.use_host_budget) {
-        excess = r.host_excess;
-        rank_off = r.host_rank_off;
-      } else {
-        // n = total + alive - too_uncertain; n = max(n - max_samples, 0)
-        excess = (long long)r.dscal[CMBPO_D_TOTAL_SAMPLES] + n - n_unc - (long long)r.max_samples;
-        if (excess < 0) excess = 0;
-      }
-    }
-    s_excess = excess;
-    s_rank_off = rank_off;
+    r.iscal[CMBPO_I_N_FIN_PRE] = n_unc;
   }
-  __syncthreads();
-  if (count_only) return;
-  const long long excess = s_excess;
-  const int rank_off = s_rank_off;
-
+  if (count_only || r.max_samples <= 0) return;
+  long long excess;
+  int rank_off = 0;
+  if (r.use_host_budget) {
+    excess = r.host_excess;
+    rank_off = r.host_rank_off;
+  } else {
+    // n = total + alive - too_uncertain; n = max(n - max_samples, 0)   (model_sampler.py:283-284)
+    excess = (long long)r.dscal[CMBPO_D_TOTAL_SAMPLES] + n - n_unc - (long long)r.max_samples;
+  }
+  if (excess <= 0) return;
   int carry = 0, nfin = 0;
   for (int base = 0; base < n; base += kScanThreads) {
     const int i = base + tid;
-    int b = -1;
-    bool unc = false;
+    int b = -1, flag = 0;
     if (i < n) {
       b = r.alive_idx[i];
-      unc = too_uncertain(r, b);
+      flag = r.fin_code[b] ? 0 : 1;
     }
-    const int flag = (i < n && !unc) ? 1 : 0;
     int total;
     const int excl = block_excl_scan(flag, sm_i, &total);
-    if (i < n) {
-      // early_term[:n] = True over the surviving rows in index order
-      const bool early = flag && ((long long)rank_off + carry + excl < excess);
-      const uint8_t code = (unc || early) ? 1 : 0;
-      r.fin_code[b] = code;
-      nfin += code;
+    // early_term[:n] = True over the surviving rows in index order
+    if (flag && ((long long)rank_off + carry + excl < excess)) {
+      r.fin_code[b] = 1;
+      nfin += 1;
     }
     carry += total;
+    if ((long long)rank_off + carry >= excess) break;   // uniform: carry is a block-wide value
   }
   const double nf = block_sum((double)nfin, sm_d);
-  if (tid == 0) r.iscal[CMBPO_I_N_FIN_PRE] = (int)nf;
+  if (tid == 0) r.iscal[CMBPO_I_N_FIN_PRE] = n_unc + (int)nf;
 }
 
 // ---- finish: reward + cost GAE, then mark terminated (modelbuffer.py:138-182) -------------------
@@ -219,6 +225,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const cmbpo_rollout_t r, in
       return;
     }
     lcv = r.vc_n[b];  // terminal branches still bootstrap the cost value (:364)
+    atomicAdd(&r.iscal[CMBPO_I_N_FIN_POST], 1);
   } else {
     if (!r.alive[b]) return;
     lv = r.v_t[b];
@@ -256,37 +263,29 @@ __global__ __launch_bounds__(256) void finish_kernel(const cmbpo_rollout_t r, in
 }
 
 // ---- store: transition -> column ptr, sampler accumulators ---------------------------------------
-constexpr int kStoreRows = 64;  // rows per workgroup (limits same-address atomics)
+constexpr int kStoreRows = 256;  // rows per workgroup
 
 __global__ __launch_bounds__(256) void store_kernel(const cmbpo_rollout_t r) {
   __shared__ double sm_d[16];
+  __shared__ int s_slot[kStoreRows];   // branch slot of each row of the tile, -1: not stored
   const int n = r.iscal[CMBPO_I_N_ALIVE];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int tid = threadIdx.x;
   const int row0 = blockIdx.x * kStoreRows;
   if (row0 >= n) return;
   const size_t B = (size_t)r.B;
   const int D = r.obs_dim, A = r.act_dim;
-  const int width = D + 3 * A;
   const double dkl_mean = r.dscal[CMBPO_D_DKL_SUM_T] / (double)n;  // np.mean over the rows stepped
   double a_cnt = 0, a_cost = 0, a_rew = 0, a_v = 0, a_vc = 0, a_epv = 0, a_maxdkl = 0, a_maxret = 0;
-  for (int k = w; k < kStoreRows; k += 4) {
-    const int i = row0 + k;
-    if (i >= n) break;
-    const int b = r.alive_idx[i];
-    if (r.fin_code[b]) continue;
-    const size_t col = (size_t)r.ptr * B + b;
-    for (int e = lane; e < width; e += 64) {
-      if (e < D) {
-        r.obs_buf[col * D + e] = r.cur_obs[(size_t)b * D + e];
-      } else if (e < D + A) {
-        r.act_buf[col * A + (e - D)] = r.act_t[(size_t)b * A + (e - D)];
-      } else if (e < D + 2 * A) {
-        r.mu_buf[col * A + (e - D - A)] = r.mu_t[(size_t)b * A + (e - D - A)];
-      } else {
-        r.ls_buf[col * A + (e - D - 2 * A)] = r.ls_t[(size_t)b * A + (e - D - 2 * A)];
-      }
+  {
+    const int i = row0 + tid;
+    int b = -1;
+    if (i < n) {
+      b = r.alive_idx[i];
+      if (r.fin_code[b]) b = -1;
     }
-    if (lane == 0) {
+    s_slot[tid] = b;
+    if (b >= 0) {
+      const size_t col = (size_t)r.ptr * B + b;
       const float rw = r.rew_t[b], c = r.cost_t[b], v = r.v_t[b], vc = r.vc_t[b];
       const float epv = r.epv_t[b], dk = r.dkl_t[b];
       r.rew_buf[col] = rw;
@@ -300,13 +299,30 @@ __global__ __launch_bounds__(256) void store_kernel(const cmbpo_rollout_t r) {
       r.path_cost[b] += (double)c;
       r.path_dyn_var[b] += (double)epv;
       r.dkl_acc[b] += (double)dk;
-      a_cnt += 1.0; a_cost += c; a_rew += rw; a_v += v; a_vc += vc;
-      a_epv += (double)epv * D;
-      a_maxdkl = fmax(a_maxdkl, (double)dk);
-      a_maxret = fmax(a_maxret, pr);
+      a_cnt = 1.0; a_cost = c; a_rew = rw; a_v = v; a_vc = vc;
+      a_epv = (double)epv * D;
+      a_maxdkl = (double)dk;
+      a_maxret = pr;
     }
   }
-  // lane 0 of each wave holds partials; reduce the 4 waves through LDS
+  __syncthreads();
+  // vector fields: consecutive threads -> consecutive elements of a row (rows of a dense alive list are
+  // adjacent slots, so both sides are contiguous)
+  const int rows_here = min(kStoreRows, n - row0);
+  const float *vsrc[4] = {r.cur_obs, r.act_t, r.mu_t, r.ls_t};
+  float *vdst[4] = {r.obs_buf, r.act_buf, r.mu_buf, r.ls_buf};
+  const int vdim[4] = {D, A, A, A};
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int dim = vdim[f];
+    const float inv = 1.0f / (float)dim;
+    for (int e = tid; e < rows_here * dim; e += 256) {
+      const int k = (int)(((float)e + 0.5f) * inv);   // exact for e < 2^16
+      const int d = e - k * dim;
+      const int b = s_slot[k];
+      if (b >= 0) vdst[f][((size_t)r.ptr * B + b) * dim + d] = vsrc[f][(size_t)b * dim + d];
+    }
+  }
   const double cnt = block_sum(a_cnt, sm_d);
   const double cost = block_sum(a_cost, sm_d);
   const double rew = block_sum(a_rew, sm_d);
@@ -315,7 +331,7 @@ __global__ __launch_bounds__(256) void store_kernel(const cmbpo_rollout_t r) {
   const double epv = block_sum(a_epv, sm_d);
   const double mdkl = block_max(a_maxdkl, sm_d);
   const double mret = block_max(a_maxret, sm_d);
-  if (threadIdx.x == 0 && cnt > 0.0) {
+  if (tid == 0 && cnt > 0.0) {
     atomicAdd(&r.iscal[CMBPO_I_N_STORED], (int)cnt);
     atomicAdd(&r.iscal[CMBPO_I_SIZE], (int)cnt);
     atomicAdd(&r.dscal[CMBPO_D_TOTAL_SAMPLES], cnt);
@@ -330,10 +346,6 @@ __global__ __launch_bounds__(256) void store_kernel(const cmbpo_rollout_t r) {
     atomic_max_nonneg(&r.dscal[CMBPO_D_MAX_DKL], mdkl);
     atomic_max_nonneg(&r.dscal[CMBPO_D_MAX_PATH_RETURN], mret);
   }
-}
-
-__global__ void clear_step_counters(const cmbpo_rollout_t r) {
-  r.iscal[CMBPO_I_N_STORED] = 0;
 }
 
 // ---- compact: ordered alive list from the alive mask ---------------------------------------------
@@ -497,21 +509,26 @@ extern "C" int cmbpo_rollout_reset(const cmbpo_rollout_t *r, void *stream) {
   return CMBPO_OK;
 }
 
+static int launch_decide(const cmbpo_rollout_t *r, int count_only, hipStream_t s) {
+  hipLaunchKernelGGL(decide_clear_kernel, dim3(1), dim3(1), 0, s, *r);
+  const int blocks = cmbpo_ceil_div(r->B, 256) < 512 ? cmbpo_ceil_div(r->B, 256) : 512;
+  hipLaunchKernelGGL(decide_flags_kernel, dim3(blocks), dim3(256), 0, s, *r);
+  hipLaunchKernelGGL(decide_budget_kernel, dim3(1), dim3(kScanThreads), 0, s, *r, count_only);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
 extern "C" int cmbpo_rollout_decide(const cmbpo_rollout_t *r, void *stream) {
   if (int rc = check_rollout(r, "cmbpo_rollout_decide")) return rc;
   CMBPO_REQUIRE(r->dkl_t && r->dkl_acc, "cmbpo_rollout_decide: NULL dkl arrays");
   CMBPO_REQUIRE(r->world >= 1 && r->rank >= 0 && r->rank < r->world, "cmbpo_rollout_decide: bad rank/world");
-  hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r, 0);
-  CMBPO_HIP_CHECK(hipGetLastError());
-  return CMBPO_OK;
+  return launch_decide(r, 0, (hipStream_t)stream);
 }
 
 extern "C" int cmbpo_rollout_count(const cmbpo_rollout_t *r, void *stream) {
   if (int rc = check_rollout(r, "cmbpo_rollout_count")) return rc;
   CMBPO_REQUIRE(r->dkl_t && r->dkl_acc, "cmbpo_rollout_count: NULL dkl arrays");
-  hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r, 1);
-  CMBPO_HIP_CHECK(hipGetLastError());
-  return CMBPO_OK;
+  return launch_decide(r, 1, (hipStream_t)stream);
 }
 
 extern "C" int cmbpo_rollout_finish(const cmbpo_rollout_t *r, int mode, void *stream) {
@@ -536,7 +553,6 @@ extern "C" int cmbpo_rollout_store(const cmbpo_rollout_t *r, void *stream) {
   CMBPO_REQUIRE(r->obs_buf && r->act_buf && r->mu_buf && r->ls_buf && r->rew_buf && r->val_buf && r->cost_buf &&
                     r->cval_buf && r->logp_buf,
                 "cmbpo_rollout_store: NULL buffer");
-  hipLaunchKernelGGL(clear_step_counters, dim3(1), dim3(1), 0, (hipStream_t)stream, *r);
   hipLaunchKernelGGL(store_kernel, dim3(cmbpo_ceil_div(r->B, kStoreRows)), dim3(256), 0, (hipStream_t)stream, *r);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;

@@ -76,8 +76,7 @@ class ModelSampler:
 
     # -- accumulators ---------------------------------------------------------------------------------
     def _read_scalars(self):
-        isc = self.pool.sync_counters()
-        dsc = self.pool.t["dscal"].cpu().numpy()
+        isc, dsc = self.pool.read_scalars()
         self._dsc = dsc
         return isc, dsc
 
@@ -209,14 +208,17 @@ class ModelSampler:
             pool._call("cmbpo_rollout_store")
             self._critics("next_obs", "v_n", "vc_n", n)
             pool._call("cmbpo_rollout_finish", 1)
-            pool._call("cmbpo_rollout_compact")
-            pool.swap("alive_idx", "alive_idx_out")
+            # the host sync of the step: counters of what finished / was stored + the accumulators
+            isc, dsc = self._read_scalars()
+            if int(isc[_lib.I_N_FIN_PRE]) + int(isc[_lib.I_N_FIN_POST]) > 0:
+                pool._call("cmbpo_rollout_compact")      # the alive list only changes when a branch finished
+                pool.swap("alive_idx", "alive_idx_out")
+                pool.sync_counters()
             pool.swap("cur_obs", "next_obs")
             pool.swap("v_t", "v_n")
             pool.swap("vc_t", "vc_n")
             pool.ptr += 1
             rs.ptr = pool.ptr
-            isc, dsc = self._read_scalars()
         self._host["total_samples"] = float(dsc[_lib.D_TOTAL_SAMPLES])
         self._host["total_dkl"] = float(dsc[_lib.D_TOTAL_DKL])
         alive = pool.n_alive

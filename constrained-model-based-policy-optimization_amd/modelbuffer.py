@@ -60,8 +60,10 @@ class ModelBuffer:
             t[name] = torch.empty((T, B), **f)
         t["alive_idx"] = torch.empty(B, dtype=torch.int32, device=dev)
         t["alive_idx_out"] = torch.empty(B, dtype=torch.int32, device=dev)
-        t["iscal"] = torch.zeros(32, dtype=torch.int32, device=dev)
-        t["dscal"] = torch.zeros(32, **d)
+        # device scalar block: int32[32] counters | float64[32] accumulators, one D2H copy reads both
+        t["scal_bytes"] = torch.zeros(32 * 4 + 32 * 8, dtype=torch.uint8, device=dev)
+        t["iscal"] = t["scal_bytes"][:128].view(torch.int32)
+        t["dscal"] = t["scal_bytes"][128:].view(torch.float64)
         t["alive"] = torch.empty(B, dtype=torch.uint8, device=dev)
         t["fin_code"] = torch.empty(B, dtype=torch.uint8, device=dev)
         t["len"] = torch.empty(B, dtype=torch.int32, device=dev)
@@ -130,12 +132,16 @@ class ModelBuffer:
         self._size = 0
 
     # ------------------------------------------------------------------------------------------
-    def sync_counters(self):
-        """One small D2H copy: alive count / buffer size as host ints."""
-        isc = self.t["iscal"].cpu()
+    def read_scalars(self):
+        """One small D2H copy (the host sync of a step): (int32 counters, float64 accumulators)."""
+        raw = self.t["scal_bytes"].cpu()
+        isc, dsc = raw[:128].view(torch.int32).numpy(), raw[128:].view(torch.float64).numpy()
         self._n_alive = int(isc[_lib.I_N_ALIVE])
         self._size = int(isc[_lib.I_SIZE])
-        return isc
+        return isc, dsc
+
+    def sync_counters(self):
+        return self.read_scalars()[0]
 
     @property
     def size(self):

@@ -189,6 +189,7 @@ typedef struct cmbpo_rollout {
 #define CMBPO_I_N_STORED 3  /* rows stored this step                            */
 #define CMBPO_I_N_ALIVE_OUT 4 /* length of alive_idx_out after compact          */
 #define CMBPO_I_SIZE 5      /* populated entries in the buffer (pool.size)      */
+#define CMBPO_I_N_FIN_POST 6 /* rows finished after the store (horizon / terminal) */
 /* dscal slots (sampler accumulators, model_sampler.py:314-333) */
 #define CMBPO_D_TOTAL_SAMPLES 0
 #define CMBPO_D_TOTAL_COST 1

@@ -233,6 +233,17 @@ def main():
     avg_ms = float(np.mean(k_ms)) if k_ms else float("nan")
     achieved = flop_per_row * float(np.mean(k_rows)) / (avg_ms * 1e-3) / 1e12 if k_ms else float("nan")
 
+    # HBM traffic of the dominant kernel: PMC counters collected offline (separate rocprofv3 --pmc passes, see
+    # profiles/r01/pmc_traffic.json), scaled to this run's rows per launch
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if task == "AntSafe-v2" and k_rows:
+            traffic = pmc["hbm_bytes_per_launch"] * float(np.mean(k_rows)) / pmc["rows_per_launch"]
+    except Exception:
+        traffic = None
+
     if rank == 0:
         out = {
             "metric": "imagined env-steps/sec (ensemble rollout) + CPO update ms",
@@ -253,7 +264,7 @@ def main():
                        "branches_per_gpu": B, "horizon": MAXROLL - 1, "task": task,
                        "samples_per_step": tot / args.steps},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "kernel": "ens_mlp_kernel<512,1,swish,prob>", "avg_launch_ms": avg_ms,
                          "launches": len(k_ms), "flop_per_branch_step": flop_per_row},
         }

@@ -139,18 +139,19 @@ class CPOPolicy:
         """cpo_policy.py:600-656: pre-measures, CPOAgent.update_pi, post-measures and deltas."""
         self._sync_ops()
         self._bind(buf_inputs)
-        pre = self.agent.measures(self.ops)
-        self.logger.store(LossPi=pre["LossPi"], SurrCost=pre["SurrCost"], SurrAdv=pre["SurrAdv"],
-                          Entropy=pre["Entropy"])
         cost = buf_inputs[9]
         cur_cost = (float(cost.mean()) if isinstance(cost, torch.Tensor) else float(np.mean(cost))) * self.max_path_length
         if cur_cost - self.cost_lim > 0 and self.agent.cares_about_cost:
             self.logger.log('Warning! Safety constraint is already violated.', 'red')
         info = self.agent.update_pi(self.ops, self.target_kl, self.cost_lim, self.real_c_buffer)
+        # pre / post measures come out of the update's own kernels (the reference spends two extra
+        # sess.run calls on them, cpo_policy.py:613-618,647-656)
+        pre, post = info["pre"], info["post"]
+        self.logger.store(LossPi=pre["LossPi"], SurrCost=pre["SurrCost"], SurrAdv=pre["SurrAdv"],
+                          Entropy=pre["Entropy"])
         # the accepted (or restored) parameters now live in ops; mirror them into the rollout actor
         self.actor.set_params(self.ops.get_params())
         self._ops_version = self.actor.version
-        post = self.agent.measures(self.ops)
         deltas = {k + "Delta": post[k] - pre[k] for k in ("LossPi", "SurrCost", "SurrAdv")}
         self.logger.store(KL=post["KL"], **deltas)
         return info

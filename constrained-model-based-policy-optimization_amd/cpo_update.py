@@ -1,17 +1,20 @@
 """CPO trust-region update -- host-side mirror of ``CPOAgent.update_pi`` (``policies/cpo_policy.py:139-300``).
 
 The reference evaluates TF graph fetches through ``sess.run`` (a full feed of the batch per call: 1 gradient
-eval, 11 or 22 Hessian-vector products, up to 11 line-search evals).  Here the batch is bound once on the
-device and each fetch is one fused HIP kernel behind the C-ABI (``csrc/policy_update.hip``):
+eval, 11 or 22 Hessian-vector products, up to 11 line-search evals) and does the vector algebra in NumPy in
+between.  Here the batch is bound once on the device, every fetch is one fused HIP kernel behind the C-ABI
+(``csrc/policy_update.hip``) and the parameter-sized vectors never leave the GPU (``csrc/vec_ops.hip``):
 
     flat_g, flat_b, pi_loss, surr_cost, cur_cret_avg  -> cmbpo_pi_loss_grad (x2)
-    Hx = hvp + damping * v                             -> cmbpo_pi_fvp
-    set_and_eval(step) -> [d_kl, pi_loss, surr_cost]   -> cmbpo_pi_set_params + cmbpo_pi_eval
+    v = cg(Hx, g), w = cg(Hx, b)                       -> 10 x [cmbpo_pi_fvp, (all-reduce), cmbpo_cg_step] each
+    q, r, s, b.b                                       -> cmbpo_vec_dots
+    set_and_eval(step) -> [d_kl, pi_loss, surr_cost]   -> cmbpo_vec_lincomb + cmbpo_pi_set_params + cmbpo_pi_eval
 
-The decision logic (c, margin, cases 0-4, dual (lam, nu), step, backtracking) is the reference's, line for
-line in meaning, on host scalars; CG (``utilities/trust_region.py:32-45``) runs on float32 host vectors.
-Reductions are sums weighted by sample counts (all-reduced over ranks when a ``dist.Comm`` is given) instead of
-``mpi_avg`` of per-rank means (``utilities/mpi_tools.py:67-69``), and counts are never cast to float32.
+Host synchronisations per update: one after the CG phase (8 scalars) and one per line-search trial (the
+accept / reject decision is the reference's, on host scalars).  The decision logic (c, margin, cases 0-4, dual
+(lam, nu), step, backtracking) follows the reference line for line in meaning.  Reductions are sums weighted
+by sample counts (all-reduced over ranks when a ``dist.Comm`` is given) instead of ``mpi_avg`` of per-rank means
+(``utilities/mpi_tools.py:67-69``), and counts are never cast to float32.
 """
 import ctypes as C
 
@@ -36,7 +39,7 @@ class _NullLogger:
 
 
 def cg(Ax, b, cg_iters=10):
-    """utilities/trust_region.py:32-45: fixed iteration count, no early exit, EPS in the step length."""
+    """Host form of utilities/trust_region.py:32-45 (kept for callers that hold NumPy vectors)."""
     x = np.zeros_like(b)
     r = b.copy()
     p = r.copy()
@@ -53,7 +56,7 @@ def cg(Ax, b, cg_iters=10):
 
 
 class PolicyOps:
-    """Device side of the update: owns the ``cmbpo_pi_t`` handle, the bound batch and scratch vectors."""
+    """Device side of the update: owns the ``cmbpo_pi_t`` handle, the bound batch and the work vectors."""
 
     def __init__(self, obs_dim, act_dim, hidden=128, device=None, comm=None):
         self.device = torch.device(device if device is not None else "cuda")
@@ -65,9 +68,13 @@ class PolicyOps:
         self.P = _lib.lib().cmbpo_pi_num_params(self._h)
         f = dict(dtype=torch.float32, device=self.device)
         self.params = torch.zeros(self.P, **f)
-        self.vec = torch.zeros(self.P, **f)
-        self.dirv = torch.zeros(self.P, **f)
+        self.vec = torch.zeros(self.P, **f)       # raw kernel output (sums over samples)
+        self.dirv = torch.zeros(self.P, **f)      # staging of host directions
+        self.work = {k: torch.zeros(self.P, **f) for k in
+                     ("g", "b", "v", "w", "hv", "hw", "cg_r", "cg_p", "x", "old", "trial")}
         self.sums = torch.zeros(8, dtype=torch.float64, device=self.device)
+        self.sums_g = torch.zeros(8, dtype=torch.float64, device=self.device)
+        self.scal = torch.zeros(16, dtype=torch.float64, device=self.device)   # [0] cg r.r ; [8..] dot products
         self.batch = _lib.PiBatchStruct()
         self._keep = None
         self.n_global = 0
@@ -80,14 +87,17 @@ class PolicyOps:
             except Exception:
                 pass
 
-    def _stream(self):
+    def _s(self):
         return _lib.current_stream()
 
+    # -- parameters ----------------------------------------------------------------------------------------
     def set_params(self, flat):
+        """flat: NumPy / torch vector [P] (host or device)."""
         with torch.cuda.device(self.device):
             t = flat if isinstance(flat, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(flat, dtype=F32))
-            self.params.copy_(t.to(self.device, torch.float32).reshape(-1))
-            _lib.check(_lib.lib().cmbpo_pi_set_params(self._h, self.params.data_ptr(), self._stream()),
+            if t.data_ptr() != self.params.data_ptr():
+                self.params.copy_(t.to(self.device, torch.float32).reshape(-1))
+            _lib.check(_lib.lib().cmbpo_pi_set_params(self._h, self.params.data_ptr(), self._s()),
                        "cmbpo_pi_set_params")
 
     def get_params(self):
@@ -114,28 +124,73 @@ class PolicyOps:
             for t in tensors:
                 self.comm.all_reduce_sum(t)
 
+    # -- device-resident building blocks ---------------------------------------------------------------------
+    def lincomb(self, out, a, x, b=0.0, y=None):
+        """out = a * x + b * y on the device."""
+        _lib.check(_lib.lib().cmbpo_vec_lincomb(self.P, float(a), x.data_ptr(), float(b),
+                                                None if y is None else y.data_ptr(), out.data_ptr(), self._s()),
+                   "cmbpo_vec_lincomb")
+        return out
+
+    def dots(self, pairs, offset=8):
+        """scal[offset + k] = x_k . y_k (device); read back with the next synchronisation."""
+        n = len(pairs)
+        xs = (C.c_void_p * n)(*[p[0].data_ptr() for p in pairs])
+        ys = (C.c_void_p * n)(*[p[1].data_ptr() for p in pairs])
+        _lib.check(_lib.lib().cmbpo_vec_dots(self.P, n, xs, ys, self.scal[offset:].data_ptr(), self._s()),
+                   "cmbpo_vec_dots")
+
+    def grad_dev(self, which, out, sums):
+        """out = grad / N on the device; `sums` (device float64[8]) gets the loss sums."""
+        _lib.check(_lib.lib().cmbpo_pi_loss_grad(self._h, C.byref(self.batch), which, self.vec.data_ptr(),
+                                                sums.data_ptr(), self._s()), "cmbpo_pi_loss_grad")
+        self._reduce(self.vec, sums)
+        return self.lincomb(out, 1.0 / float(self.n_global), self.vec)
+
+    def fvp_raw(self, v):
+        """self.vec = sum_n J^T M J v (+ log_std diagonal) for the device vector v."""
+        _lib.check(_lib.lib().cmbpo_pi_fvp(self._h, C.byref(self.batch), v.data_ptr(), self.vec.data_ptr(), self._s()),
+                   "cmbpo_pi_fvp")
+        self._reduce(self.vec)
+        return self.vec
+
+    def hx_dev(self, v, out, damping):
+        """out = Hx(v) = hvp / N + damping * v (cpo_policy.py:168, 550-552)."""
+        self.fvp_raw(v)
+        return self.lincomb(out, 1.0 / float(self.n_global), self.vec, damping, v)
+
+    def cg_dev(self, b, x, damping, iters=10):
+        """x = cg(Hx, b) (utilities/trust_region.py:32-45), entirely enqueued on the stream."""
+        lib, r, p = _lib.lib(), self.work["cg_r"], self.work["cg_p"]
+        _lib.check(lib.cmbpo_cg_init(self.P, b.data_ptr(), x.data_ptr(), r.data_ptr(), p.data_ptr(),
+                                     self.scal.data_ptr(), self._s()), "cmbpo_cg_init")
+        inv_n = 1.0 / float(self.n_global)
+        for _ in range(iters):
+            self.fvp_raw(p)
+            _lib.check(lib.cmbpo_cg_step(self.P, self.vec.data_ptr(), inv_n, float(damping), x.data_ptr(), r.data_ptr(),
+                                         p.data_ptr(), self.scal.data_ptr(), self._s()), "cmbpo_cg_step")
+        return x
+
+    def eval_dev(self, sums):
+        _lib.check(_lib.lib().cmbpo_pi_eval(self._h, C.byref(self.batch), sums.data_ptr(), self._s()), "cmbpo_pi_eval")
+        self._reduce(sums)
+        return sums
+
+    # -- NumPy-facing forms (tests, diagnostics) -----------------------------------------------------------------
     def loss_grad(self, which):
-        """(sum-gradient / N as float32 numpy, sums as float64 numpy)."""
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().cmbpo_pi_loss_grad(self._h, C.byref(self.batch), which, self.vec.data_ptr(),
-                                                    self.sums.data_ptr(), self._stream()), "cmbpo_pi_loss_grad")
-            self._reduce(self.vec, self.sums)
-            return (self.vec / float(self.n_global)).cpu().numpy(), self.sums.cpu().numpy()
+            g = self.grad_dev(which, self.work["g" if which == 0 else "b"], self.sums)
+            return g.cpu().numpy(), self.sums.cpu().numpy()
 
     def fvp(self, v):
         with torch.cuda.device(self.device):
             self.dirv.copy_(torch.from_numpy(np.ascontiguousarray(v, dtype=F32)))
-            _lib.check(_lib.lib().cmbpo_pi_fvp(self._h, C.byref(self.batch), self.dirv.data_ptr(), self.vec.data_ptr(),
-                                              self._stream()), "cmbpo_pi_fvp")
-            self._reduce(self.vec)
+            self.fvp_raw(self.dirv)
             return (self.vec / float(self.n_global)).cpu().numpy()
 
     def evals(self):
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().cmbpo_pi_eval(self._h, C.byref(self.batch), self.sums.data_ptr(), self._stream()),
-                       "cmbpo_pi_eval")
-            self._reduce(self.sums)
-            return self.sums.cpu().numpy()
+            return self.eval_dev(self.sums).cpu().numpy()
 
 
 class CPOAgent:
@@ -160,58 +215,71 @@ class CPOAgent:
     def set_logger(self, logger):
         self.logger = logger
 
-    # -- fetches ------------------------------------------------------------------------------------------
     def _ent(self, log_std):
-        return float(np.sum(log_std.astype(np.float64) + 0.5 * np.log(2 * np.pi * np.e)))   # ac_network.py:57-61
+        return float(np.sum(np.asarray(log_std, np.float64) + 0.5 * np.log(2 * np.pi * np.e)))   # ac_network.py:57-61
 
     def measures(self, ops):
         """LossPi, SurrCost, SurrAdv, Entropy, KL at the current parameters (cpo_policy.py:613-656)."""
         s = ops.evals()
         n = s[0]
-        log_std = ops.get_params()[-ops.A:]
-        ent = self._ent(log_std)
+        ent = self._ent(ops.get_params()[-ops.A:])
         surr_adv, surr_cost = s[1] / n, s[2] / n
         return dict(LossPi=F32(-(surr_adv + self.ent_reg * ent)), SurrCost=F32(surr_cost), SurrAdv=F32(surr_adv),
                     Entropy=F32(ent), KL=F32(s[3] / n))
 
     def update_pi(self, ops, target_kl, cost_lim, real_cost_buf):
-        """policies/cpo_policy.py:153-300.  `ops` is a bound PolicyOps; returns the logged scalars."""
-        A = ops.A
-        g, sg = ops.loss_grad(0)
-        b, _ = ops.loss_grad(1)
+        """policies/cpo_policy.py:153-300.  `ops` is a bound PolicyOps.
+
+        Returns the logged scalars plus `pre` / `post` measures (LossPi, SurrCost, SurrAdv, Entropy, KL) that the
+        reference obtains with extra sess.run calls around the update (cpo_policy.py:613-656)."""
+        A, wk = ops.A, ops.work
+        damping = float(F32(self.damping_coeff))
+        with torch.cuda.device(ops.device):
+            wk["old"].copy_(ops.params)
+            g = ops.grad_dev(0, wk["g"], ops.sums_g)
+            b = ops.grad_dev(1, wk["b"], ops.sums)
+            if self.ent_reg:
+                g[-A:] -= float(self.ent_reg)                       # d(-ent_reg * ent) / d log_std
+            ops.dots([(b, b)], offset=9)
+            v = ops.cg_dev(g, wk["v"], damping)                      # :210 (enqueued before the first sync)
+            sg = ops.sums_g.cpu().numpy()                             # <- host synchronisation #0: losses, b.b
+            bb = F32(ops.scal[9].item())
+            log_std = ops.params[-A:].cpu().numpy()
         n = sg[0]
-        g[-A:] -= F32(self.ent_reg)                               # d(-ent_reg * ent) / d log_std
-        ent = self._ent(ops.get_params()[-A:])
-        pi_l_old = F32(-(sg[1] / n + self.ent_reg * ent))
+        ent = self._ent(log_std)
+        surr_adv_old = sg[1] / n
+        pi_l_old = F32(-(surr_adv_old + self.ent_reg * ent))
         surr_cost_old = F32(sg[2] / n)
-        cur_cret_avg = F32(sg[4] / n * self.max_path_length)      # cpo_policy.py:533
-        damping = F32(self.damping_coeff)
+        cur_cret_avg = F32(sg[4] / n * self.max_path_length)       # cpo_policy.py:533
+        pre = dict(LossPi=pi_l_old, SurrCost=surr_cost_old, SurrAdv=F32(surr_adv_old), Entropy=F32(ent))
 
-        def Hx(x):
-            x = np.asarray(x, dtype=F32)
-            return ops.fvp(x) + damping * x                        # cpo_policy.py:550-552
-
-        old_params = ops.get_params()
         rescale = 1 / self.max_path_length
-        c = (cur_cret_avg - cost_lim) * rescale                    # :185
-        if self.learn_margin:                                      # :188-196
+        c = (cur_cret_avg - cost_lim) * rescale                     # :185
+        if self.learn_margin:                                       # :188-196
             real_c = np.mean(real_cost_buf)
             self.margin *= self.margin_discount
             self.margin += self.margin_lr * (real_c - cost_lim) * rescale
             self.margin = max(0, self.margin)
-        self.margin = F32(self.margin)                             # mpi_avg returns float32 (:201)
+        self.margin = F32(self.margin)                              # mpi_avg returns float32 (:201)
         c += self.margin
 
-        v = cg(Hx, g)                                              # :210-212
-        approx_g = Hx(v)
-        q = np.dot(v, approx_g)
-        if np.dot(b, b) <= 1e-8 and c < 0 or not self.constrained:  # :216-219
-            w, r, s, A_, B_ = 0, 0, 0, 0, 0
+        trpo_shortcut = bool(bb <= 1e-8 and c < 0 or not self.constrained)   # :216
+        with torch.cuda.device(ops.device):
+            approx_g = ops.hx_dev(v, wk["hv"], damping)              # :211
+            pairs = [(v, approx_g)]
+            if not trpo_shortcut:
+                w = ops.cg_dev(b, wk["w"], damping)                  # :222
+                hw = ops.hx_dev(w, wk["hw"], damping)
+                pairs += [(w, approx_g), (w, hw)]                    # :223-224
+            ops.dots(pairs, offset=10)
+            sc = ops.scal.cpu().numpy()                               # <- host synchronisation #1: q, r, s
+        q = F32(sc[10])
+
+        if trpo_shortcut:                                           # :216-219
+            r, s, A_, B_ = 0, 0, 0, 0
             optim_case = 4
         else:
-            w = cg(Hx, b)
-            r = np.dot(w, approx_g)
-            s = np.dot(w, Hx(w))
+            r, s = F32(sc[11]), F32(sc[12])
             A_ = q - r ** 2 / s
             B_ = 2 * target_kl - c ** 2 / s
             if c < 0 and B_ < 0:
@@ -225,7 +293,7 @@ class CPOAgent:
                 optim_case = 0
                 self.logger.log('Alert! Attempting infeasible recovery!', 'red')
 
-        if optim_case in [3, 4]:                                   # :247-262
+        if optim_case in [3, 4]:                                    # :247-262
             lam = np.sqrt(q / (2 * target_kl))
             nu = 0
         elif optim_case in [1, 2]:
@@ -242,21 +310,33 @@ class CPOAgent:
             lam = 0
             nu = np.sqrt(2 * target_kl / (s + EPS))
 
-        x = (1. / (lam + EPS)) * (v + nu * w) if optim_case > 0 else nu * w      # :266
+        # x = (1 / (lam + EPS)) * (v + nu * w) if optim_case > 0 else nu * w      (:266)
+        with torch.cuda.device(ops.device):
+            x = wk["x"]
+            if optim_case == 4 or (optim_case > 0 and nu == 0):
+                ops.lincomb(x, 1.0 / (float(lam) + EPS), wk["v"])
+            elif optim_case > 0:
+                inv = 1.0 / (float(lam) + EPS)
+                ops.lincomb(x, inv, wk["v"], inv * float(nu), wk["w"])
+            else:
+                ops.lincomb(x, float(nu), wk["w"])
         info = dict(Optim_A=A_, Optim_B=B_, Optim_c=c, Optim_q=q, Optim_r=r, Optim_s=s, Optim_Lam=lam,
                     Optim_Nu=nu, Penalty=nu, PenaltyDelta=0, Margin=self.margin, OptimCase=optim_case)
         self.logger.store(**info)
 
-        def set_and_eval(step):                                    # :278-280
-            ops.set_params(np.asarray(old_params - step * x, dtype=F32))
-            sm = ops.evals()
+        def set_and_eval(step):                                     # :278-280
+            with torch.cuda.device(ops.device):
+                ops.lincomb(ops.params, 1.0, wk["old"], -float(step), x)
+                ops.set_params(ops.params)
+                sm = ops.eval_dev(ops.sums).cpu().numpy()           # <- host synchronisation per trial
+                ls = ops.params[-A:].cpu().numpy() if self.ent_reg else log_std
             nn = sm[0]
-            ent_new = self._ent(ops.get_params()[-A:])
-            return F32(sm[3] / nn), F32(-(sm[1] / nn + self.ent_reg * ent_new)), F32(sm[2] / nn)
+            ent_new = self._ent(ls)
+            return F32(sm[3] / nn), F32(-(sm[1] / nn + self.ent_reg * ent_new)), F32(sm[2] / nn), ent_new
 
         accepted = False
-        for j in range(self.backtrack_iters):                      # :285-300
-            kl, pi_l_new, surr_cost_new = set_and_eval(step=self.backtrack_coeff ** j)
+        for j in range(self.backtrack_iters):                       # :285-300
+            kl, pi_l_new, surr_cost_new, ent_new = set_and_eval(step=self.backtrack_coeff ** j)
             if (kl <= target_kl and (pi_l_new <= pi_l_old if optim_case > 1 else True) and
                     surr_cost_new - surr_cost_old <= max(-c, 0)):
                 self.logger.log('Accepting new params at step %d of line search.' % j)
@@ -268,7 +348,10 @@ class CPOAgent:
                 self.logger.log('Line search failed! Keeping old params.')
                 self.logger.store(BacktrackIters=j)
                 info["BacktrackIters"] = j
-                kl, pi_l_new, surr_cost_new = set_and_eval(step=0.)
+                kl, pi_l_new, surr_cost_new, ent_new = set_and_eval(step=0.)
         info["accepted"] = accepted
-        info["step"] = x
+        info["step"] = x.cpu().numpy()
+        info["pre"] = pre
+        info["post"] = dict(LossPi=pi_l_new, SurrCost=surr_cost_new, KL=kl, Entropy=F32(ent_new),
+                            SurrAdv=F32(-float(pi_l_new) - self.ent_reg * ent_new))
         return info

@@ -56,19 +56,36 @@ struct PiArgs {
 };
 
 // ---- packing (device side, so set_params / FVP directions never visit the host) -------------------
-// dst[((nt*kg + g)*64 + lane)*4 + s] = src[n*sn + k*sk] for n = nt*32 + (lane&31) < n_lim, k = 8g + 4(lane>>5) + s < k_lim
-__global__ void pack_kernel(float *dst, const float *src, int n_lim, int k_lim, int sn, int sk, int kg, int n_tiles) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int total = n_tiles * kg * 256;
-  if (idx >= total) return;
-  const int s = idx & 3, lane = (idx >> 2) & 63, g = (idx >> 8) % kg, nt = (idx >> 8) / kg;
-  const int n = nt * 32 + (lane & 31), k = 8 * g + 4 * (lane >> 5) + s;
-  dst[idx] = (n < n_lim && k < k_lim) ? src[(size_t)n * sn + (size_t)k * sk] : 0.0f;
-}
+// One launch packs every piece of a flat parameter vector.  Matrix pieces:
+//   dst[off + ((nt*kg + g)*64 + lane)*4 + s] = src[n*sn + k*sk], n = nt*32 + (lane&31) < n_lim, k = 8g + 4(lane>>5) + s < k_lim
+// vector pieces (kg == 0): dst[off + i] = i < n_lim ? src[i] : 0.
+struct PackPiece {
+  int dst_off, src_off, n_lim, k_lim, sn, sk, kg, count;   // count = floats written (incl. zero padding)
+};
+struct PackPlan {
+  PackPiece piece[9];
+  int total;
+};
 
-__global__ void pack_vec_kernel(float *dst, const float *src, int n, int n_pad) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_pad) dst[i] = (i < n) ? src[i] : 0.0f;
+__global__ void pack_all_kernel(float *dst, const float *flat, const PackPlan plan) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= plan.total) return;
+  int q = 0;
+  while (q < 8 && idx >= plan.piece[q].count) {
+    idx -= plan.piece[q].count;
+    ++q;
+  }
+  const PackPiece pc = plan.piece[q];
+  const float *src = flat + pc.src_off;
+  float v;
+  if (pc.kg == 0) {
+    v = (idx < pc.n_lim) ? src[idx] : 0.0f;
+  } else {
+    const int s = idx & 3, lane = (idx >> 2) & 63, g = (idx >> 8) % pc.kg, nt = (idx >> 8) / pc.kg;
+    const int n = nt * 32 + (lane & 31), k = 8 * g + 4 * (lane >> 5) + s;
+    v = (n < pc.n_lim && k < pc.k_lim) ? src[(size_t)n * pc.sn + (size_t)k * pc.sk] : 0.0f;
+  }
+  dst[pc.dst_off + idx] = v;
 }
 
 // ---- tile helpers -------------------------------------------------------------------------------------
@@ -443,22 +460,25 @@ PiPack pack_ptrs(const cmbpo_pi *h, const float *base) {
 
 int do_pack(const cmbpo_pi *h, float *dst, const float *flat, hipStream_t s) {
   const PiDims &d = h->d;
-  auto pk = [&](size_t off, const float *src, int n_lim, int k_lim, int sn, int sk, int kg, int nt) {
-    const int total = nt * kg * 256;
-    hipLaunchKernelGGL(pack_kernel, dim3(cmbpo_ceil_div(total, 256)), dim3(256), 0, s, dst + off, src, n_lim, k_lim, sn,
-                       sk, kg, nt);
+  PackPlan plan;
+  int q = 0, total = 0;
+  auto add = [&](size_t off, int src_off, int n_lim, int k_lim, int sn, int sk, int kg, int count) {
+    plan.piece[q++] = PackPiece{(int)off, src_off, n_lim, k_lim, sn, sk, kg, count};
+    total += count;
   };
   // forward packs: A[i = out unit][k = in unit] = W[k][i]
-  pk(h->off_F0, flat + d.oW0, HID, d.D, 1, HID, d.kg0, 4);
-  pk(h->off_F1, flat + d.oW1, HID, HID, 1, HID, KGH, 4);
-  pk(h->off_F2, flat + d.oW2, d.A, HID, 1, d.A, KGH, 1);
+  add(h->off_F0, d.oW0, HID, d.D, 1, HID, d.kg0, 4 * d.kg0 * 256);
+  add(h->off_F1, d.oW1, HID, HID, 1, HID, KGH, 4 * KGH * 256);
+  add(h->off_F2, d.oW2, d.A, HID, 1, d.A, KGH, KGH * 256);
   // backward packs: A[i = in unit][k = out unit] = W[i][k]
-  pk(h->off_B1, flat + d.oW1, HID, HID, HID, 1, KGH, 4);
-  pk(h->off_B2, flat + d.oW2, HID, d.A, d.A, 1, d.kga, 4);
-  hipLaunchKernelGGL(pack_vec_kernel, dim3(1), dim3(128), 0, s, dst + h->off_b0, flat + d.ob0, HID, HID);
-  hipLaunchKernelGGL(pack_vec_kernel, dim3(1), dim3(128), 0, s, dst + h->off_b1, flat + d.ob1, HID, HID);
-  hipLaunchKernelGGL(pack_vec_kernel, dim3(1), dim3(32), 0, s, dst + h->off_b2, flat + d.ob2, d.A, 32);
-  hipLaunchKernelGGL(pack_vec_kernel, dim3(1), dim3(32), 0, s, dst + h->off_ls, flat + d.ols, d.A, 32);
+  add(h->off_B1, d.oW1, HID, HID, HID, 1, KGH, 4 * KGH * 256);
+  add(h->off_B2, d.oW2, HID, d.A, d.A, 1, d.kga, 4 * d.kga * 256);
+  add(h->off_b0, d.ob0, HID, 0, 0, 0, 0, HID);
+  add(h->off_b1, d.ob1, HID, 0, 0, 0, 0, HID);
+  add(h->off_b2, d.ob2, d.A, 0, 0, 0, 0, 32);
+  add(h->off_ls, d.ols, d.A, 0, 0, 0, 0, 32);
+  plan.total = total;
+  hipLaunchKernelGGL(pack_all_kernel, dim3(cmbpo_ceil_div(total, 256)), dim3(256), 0, s, dst, flat, plan);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }

@@ -322,6 +322,21 @@ int cmbpo_gae_segments(int n_paths, const int32_t *d_offsets, const float *d_rew
  * [3] cadv_mean. */
 int cmbpo_adv_normalize(int n, float *d_adv, float *d_cadv, double *d_stats, void *stream);
 
+/* Parameter-vector algebra of the update kept on the device (csrc/vec_ops.hip).
+ * cg_init / cg_step are utilities/trust_region.py:32-45 (x = 0, r = p = b; then per
+ * iteration z = hp_sum * inv_n + damping * p, alpha = rr / (p.z + 1e-8), x += alpha p,
+ * r -= alpha z, p = r + (rr_new / rr) p); d_scal[0] carries r.r.  d_hp_sum is the raw
+ * cmbpo_pi_fvp output for direction d_p. */
+int cmbpo_cg_init(int P, const float *d_b, float *d_x, float *d_r, float *d_p, double *d_scal, void *stream);
+int cmbpo_cg_step(int P, const float *d_hp_sum, double inv_n, float damping, float *d_x, float *d_r,
+                  float *d_p, double *d_scal, void *stream);
+/* d_out = a * d_x + b * d_y (d_y may be NULL): Hx = hvp / N + damping v, the step x = (v + nu w) / (lam + eps)
+ * (policies/cpo_policy.py:266) and the trial parameters old - step * x (:278). */
+int cmbpo_vec_lincomb(int P, float a, const float *d_x, float b, const float *d_y, float *d_out, void *stream);
+/* d_out[k] = sum_i x_k[i] * y_k[i], k < n <= 8 (q, r, s, b.b of policies/cpo_policy.py:212-226); h_x / h_y are
+ * host arrays of device pointers. */
+int cmbpo_vec_dots(int P, int n, const float *const *h_x, const float *const *h_y, double *d_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,7 +86,7 @@ def build_hip(w, task, B, device, comm=None):
 def rollout_phase(sampler, pool, start):
     """reset -> sample until everything is finished -> finish_all_paths -> get(); returns samples."""
     sampler.reset(start)
-    while pool.n_alive > 0:
+    while sampler.any_alive():
         sampler.sample()
     diag = sampler.finish_all_paths()
     res, bdiag = pool.get(as_tensors=True)

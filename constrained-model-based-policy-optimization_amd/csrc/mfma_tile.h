@@ -22,11 +22,14 @@ __device__ __forceinline__ void mfma_block(const f32x4 (&a)[NT], const f32x4 (&b
         acc[t][bt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s], b[bt][s], acc[t][bt], 0, 0, 0);
 }
 
-template <int NT, int BT>
+// ROWS == false: B operand in the T-layout (float4 [k/4][BB]).  ROWS == true: B operand in a row layout
+// [b][row_stride] of floats (k contiguous per sample); with row_stride / 4 odd (132, 36, 52, ...) the per-lane
+// 16-B reads of a wave fall on distinct banks, so the same image also serves the weight-gradient MFMAs.
+template <int NT, int BT, bool ROWS = false>
 __device__ __forceinline__ void mfma_layer(const f32x4 *__restrict__ wp,
                                            size_t nt_stride, int g0, int g1,
                                            const f32x4 *lds_in, int lane,
-                                           f32x16 (&acc)[NT][BT]) {
+                                           f32x16 (&acc)[NT][BT], int row_stride = 0) {
   constexpr int BB = 32 * BT;
   const int j = lane & 31, h = lane >> 5;
   // Software pipeline, one k-group deep, ping-pong register sets (no copies): the A fragments (global / L2)
@@ -36,12 +39,16 @@ __device__ __forceinline__ void mfma_layer(const f32x4 *__restrict__ wp,
   // exposed once per k-group; everything else (address arithmetic, loop control) may interleave freely.
   f32x4 a0[NT], a1[NT], b0[BT], b1[BT];
   const f32x4 *lds_lane = lds_in + h * BB + j;
+  const float *row_lane = reinterpret_cast<const float *>(lds_in) + j * row_stride + 4 * h;
   auto request = [&](int g, f32x4 (&a)[NT], f32x4 (&b)[BT]) {
     const f32x4 *wg = wp + (size_t)g * 64;          // wave-uniform: scalar pointer arithmetic
 #pragma unroll
     for (int t = 0; t < NT; ++t) a[t] = (wg + t * nt_stride)[lane];
 #pragma unroll
-    for (int bt = 0; bt < BT; ++bt) b[bt] = lds_lane[2 * g * BB + bt * 32];
+    for (int bt = 0; bt < BT; ++bt) {
+      if constexpr (!ROWS) b[bt] = lds_lane[2 * g * BB + bt * 32];
+      else b[bt] = *reinterpret_cast<const f32x4 *>(row_lane + bt * 32 * row_stride + 8 * g);
+    }
   };
   request(g0, a0, b0);
   int g = g0;

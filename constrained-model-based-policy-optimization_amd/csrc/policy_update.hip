@@ -137,11 +137,10 @@ __device__ __forceinline__ f32x16 load_bias(const float *b, int n_base, int lane
 __device__ __forceinline__ void wgrad_tile(f32x16 &acc, const float *X, int sx, int i0, const float *Y, int sy, int j0,
                                            int lane) {
   const int i = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int s2 = 0; s2 < BB / 2; ++s2) {
-    const int b = 2 * s2 + h;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(X[b * sx + i0 + i], Y[b * sy + j0 + i], acc, 0, 0, 0);
-  }
+  const float *xp = X + h * sx + i0 + i, *yp = Y + h * sy + j0 + i;
+#pragma unroll 4
+  for (int s2 = 0; s2 < BB / 2; ++s2)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xp[2 * s2 * sx], yp[2 * s2 * sy], acc, 0, 0, 0);
 }
 
 // sum over the 32 lanes that share h (the sample index) -> valid in lane j == 0 of each half
@@ -157,111 +156,132 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kThreads, 1) void pi_kernel(const PiArgs p) {
+// load the activation tile rows n_base.. of this wave's columns from a row-layout image
+__device__ __forceinline__ f32x16 load_tile_R(const float *ldsR, int strideR, int n_base, int lane) {
+  const int j = lane & 31, h = lane >> 5;
+  f32x16 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 x = *reinterpret_cast<const f32x4 *>(ldsR + j * strideR + n_base + 8 * q + 4 * h);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v[4 * q + s] = x[s];
+  }
+  return v;
+}
+
+__device__ __forceinline__ void store_tile_R(const f32x16 &v, int n_base, float *ldsR, int strideR, int lane) {
+  const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 x;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) x[s] = v[4 * q + s];
+    *reinterpret_cast<f32x4 *>(ldsR + j * strideR + n_base + 8 * q + 4 * h) = x;
+  }
+}
+
+// Every activation image lives in LDS ONCE, in the row layout [sample][RS] (RS / 4 odd): it is the B operand of
+// the forward / JVP / backward chains (conflict-free 16-B reads, mfma_layer<.., ROWS = true>) and the A / B
+// operand of the weight-gradient MFMAs (conflict-free 4-B reads).  76.8 KB per workgroup -> two per CU.
+template <int MODE, int N_IT>
+__global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
   extern __shared__ f32x4 smem4[];
   const PiDims d = p.d;
   float *sm = reinterpret_cast<float *>(smem4);
-  // LDS map (floats); every region is a multiple of 4 floats
-  float *xT = sm;                              // [in_pad/4][BB] float4
-  float *h1T = xT + d.in_pad * BB;             // [32][BB] float4
-  float *h2T = h1T + HID * BB;
-  float *u1T = h2T + HID * BB;                 // dh1 (T) -- later d1R (row layout, BB*RS floats)
-  float *u2T = u1T + BB * RS;                  // dh2 (T), then delta2 (T)
-  float *wT = u2T + HID * BB;                  // cotangent on mu, [a_kpad/4][BB] float4; GRAD/EVAL scratch [a][b]
-  float *xR = wT + 32 * BB;                    // [BB][in_pad + 4]
-  float *h1R = xR + BB * (d.in_pad + 4);       // [BB][RS]
-  float *h2R = h1R + BB * RS;
-  float *d2R = h2R + BB * RS;                  // delta2 rows -- first the split-K reduction image (4*32*33 floats)
-  float *wR = d2R + BB * RS;                   // [BB][36]
-  float *d1R = u1T;
-  float *red = d2R;
   const int XS = d.in_pad + 4;
+  float *xR = sm;                       // [BB][XS]
+  float *h1R = xR + BB * XS;            // [BB][RS]
+  float *h2R = h1R + BB * RS;
+  float *u1R = h2R + BB * RS;           // dh1, then the split-K reduction image (4*32*33 floats), then delta1
+  float *u2R = u1R + BB * RS;           // dh2, then delta2
+  float *wR = u2R + BB * RS;            // [BB][36] cotangent on mu; GRAD / EVAL scratch before that
+  float *red = u1R;
+  float *d1R = u1R;
+  float *d2R = u2R;
+  const f32x4 *xR4 = reinterpret_cast<const f32x4 *>(xR), *h1R4 = reinterpret_cast<const f32x4 *>(h1R),
+              *h2R4 = reinterpret_cast<const f32x4 *>(h2R), *u1R4 = reinterpret_cast<const f32x4 *>(u1R),
+              *u2R4 = reinterpret_cast<const f32x4 *>(u2R), *wR4 = reinterpret_cast<const f32x4 *>(wR);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
   const int n_tiles = (p.n + BB - 1) / BB;
 
   // persistent accumulators
-  f32x16 gW1[4], gW0[2], gW2, gb1p, gb0p;
+  f32x16 gW1[4], gW0[N_IT], gW2;
 #pragma unroll
   for (int t = 0; t < 4; ++t) zero(gW1[t]);
-  zero(gW0[0]); zero(gW0[1]); zero(gW2); zero(gb1p); zero(gb0p);
+#pragma unroll
+  for (int t = 0; t < N_IT; ++t) zero(gW0[t]);
+  zero(gW2);
+  float gbias = 0.0f;   // thread n < 128: d/d b1[n]; thread 128 + n: d/d b0[n] (column sums of the delta images)
   float gb2p[4] = {0, 0, 0, 0}, glsp[4] = {0, 0, 0, 0};   // per (a = tid/32 + 8*it) partials over this thread's b
   double s_n = 0, s_ra = 0, s_rc = 0, s_kl = 0, s_cost = 0;
 
-  // zero the padded cotangent rows once (a in [A, 32)): nothing else ever writes them
-  for (int i = tid; i < 32 * BB; i += kThreads) wT[i] = 0.0f;
+  // zero the padded cotangent columns once (a in [A, 36)): nothing else ever writes them
   for (int i = tid; i < BB * 36; i += kThreads) wR[i] = 0.0f;
   __syncthreads();
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int row0 = tile * BB;
-    // ---- stage x: T-layout (B operand) and row layout (weight-gradient operand) ------------------
+    // ---- stage x in the row layout (zero padded) ------------------------------------------------------
     for (int i = tid; i < d.in_pad * BB; i += kThreads) {
       const int b = i / d.in_pad, k = i - b * d.in_pad;
       const int r = row0 + b;
-      const float v = (r < p.n && k < d.D) ? p.obs[(size_t)r * d.D + k] : 0.0f;
-      xT[((k >> 2) * BB + b) * 4 + (k & 3)] = v;
-      xR[b * XS + k] = v;
+      xR[b * XS + k] = (r < p.n && k < d.D) ? p.obs[(size_t)r * d.D + k] : 0.0f;
     }
     __syncthreads();
     // ---- forward ------------------------------------------------------------------------------------
     f32x16 acc[1][1];
-    zero(acc[0][0]);
-    mfma_layer<1, 1>(p.w.F0 + (size_t)wave * d.kg0 * 64, 0, 0, d.kg0, reinterpret_cast<f32x4 *>(xT), lane, acc);
+    acc[0][0] = load_bias(p.w.b0, wave * 32, lane);
+    mfma_layer<1, 1, true>(p.w.F0 + (size_t)wave * d.kg0 * 64, 0, 0, d.kg0, xR4, lane, acc, XS);
     {
-      const f32x16 bv = load_bias(p.w.b0, wave * 32, lane);
       f32x16 hv;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hv[r] = tanhf(acc[0][0][r] + bv[r]);
-      store_tile<true, true>(hv, wave * 32, reinterpret_cast<f32x4 *>(h1T), h1R, RS, lane);
+      for (int r = 0; r < 16; ++r) hv[r] = tanhf(acc[0][0][r]);
+      store_tile_R(hv, wave * 32, h1R, RS, lane);
     }
     __syncthreads();
-    zero(acc[0][0]);
-    mfma_layer<1, 1>(p.w.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, reinterpret_cast<f32x4 *>(h1T), lane, acc);
+    acc[0][0] = load_bias(p.w.b1, wave * 32, lane);
+    mfma_layer<1, 1, true>(p.w.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, h1R4, lane, acc, RS);
     {
-      const f32x16 bv = load_bias(p.w.b1, wave * 32, lane);
       f32x16 hv;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hv[r] = tanhf(acc[0][0][r] + bv[r]);
-      store_tile<true, true>(hv, wave * 32, reinterpret_cast<f32x4 *>(h2T), h2R, RS, lane);
+      for (int r = 0; r < 16; ++r) hv[r] = tanhf(acc[0][0][r]);
+      store_tile_R(hv, wave * 32, h2R, RS, lane);
     }
     __syncthreads();
 
     if constexpr (MODE == MODE_FVP) {
       // ---- JVP chain: dh1 = (1-h1^2)(x dW0 + db0) ; dh2 = (1-h2^2)(dh1 W1 + h1 dW1 + db1) -----------
-      zero(acc[0][0]);
-      mfma_layer<1, 1>(p.v.F0 + (size_t)wave * d.kg0 * 64, 0, 0, d.kg0, reinterpret_cast<f32x4 *>(xT), lane, acc);
+      acc[0][0] = load_bias(p.v.b0, wave * 32, lane);
+      mfma_layer<1, 1, true>(p.v.F0 + (size_t)wave * d.kg0 * 64, 0, 0, d.kg0, xR4, lane, acc, XS);
       {
-        const f32x16 bv = load_bias(p.v.b0, wave * 32, lane);
-        const f32x16 hh = load_tile_T(reinterpret_cast<f32x4 *>(h1T), wave * 32, lane);
+        const f32x16 hh = load_tile_R(h1R, RS, wave * 32, lane);
         f32x16 o;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = (1.0f - hh[r] * hh[r]) * (acc[0][0][r] + bv[r]);
-        store_tile<true, false>(o, wave * 32, reinterpret_cast<f32x4 *>(u1T), nullptr, 0, lane);
+        for (int r = 0; r < 16; ++r) o[r] = (1.0f - hh[r] * hh[r]) * acc[0][0][r];
+        store_tile_R(o, wave * 32, u1R, RS, lane);
       }
       __syncthreads();
-      zero(acc[0][0]);
-      mfma_layer<1, 1>(p.w.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, reinterpret_cast<f32x4 *>(u1T), lane, acc);
-      mfma_layer<1, 1>(p.v.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, reinterpret_cast<f32x4 *>(h1T), lane, acc);
+      acc[0][0] = load_bias(p.v.b1, wave * 32, lane);
+      mfma_layer<1, 1, true>(p.w.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, u1R4, lane, acc, RS);
+      mfma_layer<1, 1, true>(p.v.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, h1R4, lane, acc, RS);
       {
-        const f32x16 bv = load_bias(p.v.b1, wave * 32, lane);
-        const f32x16 hh = load_tile_T(reinterpret_cast<f32x4 *>(h2T), wave * 32, lane);
+        const f32x16 hh = load_tile_R(h2R, RS, wave * 32, lane);
         f32x16 o;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = (1.0f - hh[r] * hh[r]) * (acc[0][0][r] + bv[r]);
-        store_tile<true, false>(o, wave * 32, reinterpret_cast<f32x4 *>(u2T), nullptr, 0, lane);
+        for (int r = 0; r < 16; ++r) o[r] = (1.0f - hh[r] * hh[r]) * acc[0][0][r];
+        store_tile_R(o, wave * 32, u2R, RS, lane);
       }
-      __syncthreads();
+      __syncthreads();   // dh2 complete; every wave is done reading dh1 (u1R becomes the reduction image)
       // dmu = dh2 W2 + h2 dW2 (+ db2): K split over the 4 waves
       zero(acc[0][0]);
-      mfma_layer<1, 1>(p.w.F2, 0, wave * 4, wave * 4 + 4, reinterpret_cast<f32x4 *>(u2T), lane, acc);
-      mfma_layer<1, 1>(p.v.F2, 0, wave * 4, wave * 4 + 4, reinterpret_cast<f32x4 *>(h2T), lane, acc);
+      mfma_layer<1, 1, true>(p.w.F2, 0, wave * 4, wave * 4 + 4, u2R4, lane, acc, RS);
+      mfma_layer<1, 1, true>(p.v.F2, 0, wave * 4, wave * 4 + 4, h2R4, lane, acc, RS);
     } else {
       // mu = h2 W2 (+ b2): K split over the 4 waves
       zero(acc[0][0]);
-      mfma_layer<1, 1>(p.w.F2, 0, wave * 4, wave * 4 + 4, reinterpret_cast<f32x4 *>(h2T), lane, acc);
+      mfma_layer<1, 1, true>(p.w.F2, 0, wave * 4, wave * 4 + 4, h2R4, lane, acc, RS);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -273,11 +293,12 @@ __global__ __launch_bounds__(kThreads, 1) void pi_kernel(const PiArgs p) {
     // ---- element phase over (a, b): this thread owns b = tid & 31, a = tid/32 + 8*it ------------------
     const int eb = tid & 31, er = row0 + eb;
     const bool valid = er < p.n;
-    float z_[4], mu_[4], term_[4];
+    float z_[4], mu_[4];
+    float logp_part = 0.0f;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int a = (tid >> 5) + 8 * it;
-      z_[it] = mu_[it] = term_[it] = 0.0f;
+      z_[it] = mu_[it] = 0.0f;
       if (a < d.A) {
         float m = red[(0 * 32 + a) * RED_LD + eb];
         m += red[(1 * 32 + a) * RED_LD + eb];
@@ -292,27 +313,27 @@ __global__ __launch_bounds__(kThreads, 1) void pi_kernel(const PiArgs p) {
             cot = m / v1;
             glsp[it] += 2.0f * expf(2.0f * p.w.ls[a]) / v1;     // d2 KL / d log_std^2
           }
-          wT[((a >> 2) * BB + eb) * 4 + (a & 3)] = cot;
           wR[eb * 36 + a] = cot;
           gb2p[it] += cot;
         } else {
           m += p.w.b2[a];
           mu_[it] = m;
+          float term = 0.0f;
           if (valid) {
             const float ls = p.w.ls[a];
             const float sd = expf(ls) + 1e-8f;
             const float z = (p.act[(size_t)er * d.A + a] - m) / sd;
             z_[it] = z;
-            term_[it] = -0.5f * (z * z + 2.0f * ls + 1.8378770664093453f);   // gaussian_likelihood :46-48
+            term = -0.5f * (z * z + 2.0f * ls + 1.8378770664093453f);   // gaussian_likelihood :46-48
           }
-          u1T[a * BB + eb] = term_[it];   // scratch image [a][b] (u1T is idle outside the FVP)
+          wR[eb * 36 + a] = term;   // scratch: per-(b, a) log-likelihood terms
         }
       }
     }
     if constexpr (MODE != MODE_FVP) {
       __syncthreads();
-      float logp = 0.0f;
-      for (int a = 0; a < d.A; ++a) logp += u1T[a * BB + eb];
+      float logp = logp_part;
+      for (int a = 0; a < d.A; ++a) logp += wR[eb * 36 + a];
       const float ratio = valid ? expf(logp - p.logp_old[er]) : 0.0f;        // cpo_policy.py:522
       const float adv = valid ? p.adv[er] : 0.0f, cadv = valid ? p.cadv[er] : 0.0f;
       if (tid < 32 && valid) {
@@ -321,7 +342,7 @@ __global__ __launch_bounds__(kThreads, 1) void pi_kernel(const PiArgs p) {
         s_rc += (double)(ratio * cadv);
         s_cost += (double)p.cost[er];
       }
-      __syncthreads();   // every thread has read the scratch image before it is overwritten
+      __syncthreads();   // every thread has read the scratch terms before they are overwritten
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int a = (tid >> 5) + 8 * it;
@@ -340,7 +361,6 @@ __global__ __launch_bounds__(kThreads, 1) void pi_kernel(const PiArgs p) {
             const float sd = expf(ls);
             const float inv = 1.0f / (sd + 1e-8f);
             const float cot = wgt * ratio * z_[it] * inv;                    // d logp / d mu = z / (sd + eps)
-            wT[((a >> 2) * BB + eb) * 4 + (a & 3)] = cot;
             wR[eb * 36 + a] = cot;
             gb2p[it] += cot;
             glsp[it] += wgt * ratio * (z_[it] * z_[it] * sd * inv - 1.0f);  // d logp / d log_std
@@ -353,37 +373,40 @@ __global__ __launch_bounds__(kThreads, 1) void pi_kernel(const PiArgs p) {
 
     // ---- backward: delta2 = (W2 cot) (1-h2^2) ; delta1 = (W1 delta2) (1-h1^2) --------------------------
     zero(acc[0][0]);
-    mfma_layer<1, 1>(p.w.B2 + (size_t)wave * d.kga * 64, 0, 0, d.kga, reinterpret_cast<f32x4 *>(wT), lane, acc);
+    mfma_layer<1, 1, true>(p.w.B2 + (size_t)wave * d.kga * 64, 0, 0, d.kga, wR4, lane, acc, 36);
     {
-      const f32x16 hh = load_tile_T(reinterpret_cast<f32x4 *>(h2T), wave * 32, lane);
+      const f32x16 hh = load_tile_R(h2R, RS, wave * 32, lane);
       f32x16 o;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        o[r] = (1.0f - hh[r] * hh[r]) * acc[0][0][r];
-        gb1p[r] += o[r];
-      }
-      store_tile<true, true>(o, wave * 32, reinterpret_cast<f32x4 *>(u2T), d2R, RS, lane);
+      for (int r = 0; r < 16; ++r) o[r] = (1.0f - hh[r] * hh[r]) * acc[0][0][r];
+      store_tile_R(o, wave * 32, d2R, RS, lane);     // dh2 is dead (the barrier after the reduction image)
     }
     __syncthreads();
     zero(acc[0][0]);
-    mfma_layer<1, 1>(p.w.B1 + (size_t)wave * KGH * 64, 0, 0, KGH, reinterpret_cast<f32x4 *>(u2T), lane, acc);
+    mfma_layer<1, 1, true>(p.w.B1 + (size_t)wave * KGH * 64, 0, 0, KGH, u2R4, lane, acc, RS);
     {
-      const f32x16 hh = load_tile_T(reinterpret_cast<f32x4 *>(h1T), wave * 32, lane);
+      const f32x16 hh = load_tile_R(h1R, RS, wave * 32, lane);
       f32x16 o;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        o[r] = (1.0f - hh[r] * hh[r]) * acc[0][0][r];
-        gb0p[r] += o[r];
-      }
-      store_tile<false, true>(o, wave * 32, nullptr, d1R, RS, lane);
+      for (int r = 0; r < 16; ++r) o[r] = (1.0f - hh[r] * hh[r]) * acc[0][0][r];
+      store_tile_R(o, wave * 32, d1R, RS, lane);     // the reduction image is dead (element phase barrier)
     }
     __syncthreads();
     // ---- weight gradients: K = the tile's samples ---------------------------------------------------
 #pragma unroll
     for (int J = 0; J < 4; ++J) wgrad_tile(gW1[J], h1R, RS, wave * 32, d2R, RS, J * 32, lane);
-    wgrad_tile(gW0[0], xR, XS, 0, d1R, RS, wave * 32, lane);
-    if (d.n_it > 1) wgrad_tile(gW0[1], xR, XS, 32, d1R, RS, wave * 32, lane);
+#pragma unroll
+    for (int t = 0; t < N_IT; ++t) wgrad_tile(gW0[t], xR, XS, 32 * t, d1R, RS, wave * 32, lane);
     wgrad_tile(gW2, h2R, RS, wave * 32, wR, 36, 0, lane);
+    {
+      // bias gradients: column sums over the tile's samples (conflict-free: adjacent threads, adjacent columns)
+      const float *img = (tid < HID) ? d2R : d1R;
+      const int n = tid & (HID - 1);
+      float sb = 0.0f;
+#pragma unroll 8
+      for (int b = 0; b < BB; ++b) sb += img[b * RS + n];
+      gbias += sb;
+    }
     __syncthreads();
   }
 
@@ -395,15 +418,12 @@ __global__ __launch_bounds__(kThreads, 1) void pi_kernel(const PiArgs p) {
 #pragma unroll
       for (int J = 0; J < 4; ++J)
         atomicAdd(&p.vec[d.oW1 + (wave * 32 + row) * HID + J * 32 + j], gW1[J][r]);
-      if (row < d.D) atomicAdd(&p.vec[d.oW0 + row * HID + wave * 32 + j], gW0[0][r]);
-      if (d.n_it > 1 && 32 + row < d.D) atomicAdd(&p.vec[d.oW0 + (32 + row) * HID + wave * 32 + j], gW0[1][r]);
+#pragma unroll
+      for (int t = 0; t < N_IT; ++t)
+        if (32 * t + row < d.D) atomicAdd(&p.vec[d.oW0 + (32 * t + row) * HID + wave * 32 + j], gW0[t][r]);
       if (j < d.A) atomicAdd(&p.vec[d.oW2 + (wave * 32 + row) * d.A + j], gW2[r]);
-      const float s1 = half_sum(gb1p[r]), s0 = half_sum(gb0p[r]);
-      if (j == 0) {
-        atomicAdd(&p.vec[d.ob1 + wave * 32 + row], s1);
-        atomicAdd(&p.vec[d.ob0 + wave * 32 + row], s0);
-      }
     }
+    atomicAdd(&p.vec[(tid < HID ? d.ob1 : d.ob0) + (tid & (HID - 1))], gbias);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int a = (tid >> 5) + 8 * it;
@@ -484,14 +504,13 @@ int do_pack(const cmbpo_pi *h, float *dst, const float *flat, hipStream_t s) {
 }
 
 size_t lds_bytes(const PiDims &d) {
-  const size_t f = (size_t)d.in_pad * BB + 2 * HID * BB + BB * RS + HID * BB + 32 * BB + BB * (d.in_pad + 4) +
-                   3 * BB * RS + BB * 36;
+  const size_t f = (size_t)BB * (d.in_pad + 4) + 4 * BB * RS + BB * 36;
   return f * sizeof(float);
 }
 
-template <int MODE>
-int launch_pi(cmbpo_pi *h, PiArgs &a, hipStream_t s) {
-  auto kern = pi_kernel<MODE>;
+template <int MODE, int N_IT>
+int launch_pi_n(cmbpo_pi *h, PiArgs &a, hipStream_t s) {
+  auto kern = pi_kernel<MODE, N_IT>;
   static size_t attr_bytes = 0;   // the kernel also has a few bytes of static LDS: ask for what is needed
   const size_t lds = lds_bytes(h->d);
   if (lds > attr_bytes) {
@@ -500,10 +519,16 @@ int launch_pi(cmbpo_pi *h, PiArgs &a, hipStream_t s) {
     attr_bytes = lds;
   }
   const int tiles = cmbpo_ceil_div(a.n, BB);
-  const int grid = tiles < h->n_cu ? tiles : h->n_cu;
+  const int resident = 2 * h->n_cu;   // two 76.8 KB workgroups per CU
+  const int grid = tiles < resident ? tiles : resident;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, s, a);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
+}
+
+template <int MODE>
+int launch_pi(cmbpo_pi *h, PiArgs &a, hipStream_t s) {
+  return h->d.n_it > 1 ? launch_pi_n<MODE, 2>(h, a, s) : launch_pi_n<MODE, 1>(h, a, s);
 }
 
 int fill_args(cmbpo_pi *h, const cmbpo_pi_batch_t *b, PiArgs &a, const char *who) {

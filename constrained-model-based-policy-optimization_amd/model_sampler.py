@@ -145,6 +145,7 @@ class ModelSampler:
             # critics at the start states: v_t / vc_t of the first step
             self._critics("cur_obs", "v_t", "vc_t", self.batch_size)
         self._n_episodes = 0
+        self.global_alive = 1
         self._host = dict(total_samples=0.0, total_dkl=0.0)
         elites = np.asarray(self.env._model.elite_inds, dtype=np.int32)
         self._elites = torch.as_tensor(elites, device=self.device)
@@ -165,6 +166,10 @@ class ModelSampler:
         """
         pool, env, pol = self.pool, self.env, self.policy
         assert pool.has_room                       # pool full! empty before sampling.
+        sharded = self.comm is not None and self.comm.world > 1
+        if sharded and pool.n_alive == 0:
+            # this shard has nothing left but the others may: keep the collectives of the step matched
+            return self._idle_step(max_samples)
         assert pool.n_alive > 0                    # reset before sampling !
         self._n_episodes += 1
         t, rs = pool.t, pool.rs
@@ -225,11 +230,30 @@ class ModelSampler:
         if self.comm is not None and self.comm.world > 1:
             g = self.comm.all_reduce_host([alive, self.batch_size, self._host["total_samples"]])
             alive_ratio, self._global_total_samples = g[0] / g[1], g[2]
+            self.global_alive = int(g[0])
         else:
             alive_ratio = alive / self.batch_size
         info = {"alive_ratio": alive_ratio, "ensemble_dkl_path": t["dkl_t"], "cost": t["cost_t"]}
         # after the swap the step's next_obs is the new cur_obs
         return t["cur_obs"], t["rew_t"], t["term_t"], info
+
+    def _idle_step(self, max_samples):
+        pool, t = self.pool, self.pool.t
+        with torch.cuda.device(self.device):
+            if max_samples:
+                pool.rs.max_samples = int(max_samples)
+                pool._call("cmbpo_rollout_count")
+                self.comm.all_gather_i32(t["iscal"][8:12])
+        g = self.comm.all_reduce_host([0, self.batch_size, self._host["total_samples"]])
+        self.global_alive, self._global_total_samples = int(g[0]), g[2]
+        info = {"alive_ratio": g[0] / g[1], "ensemble_dkl_path": t["dkl_t"], "cost": t["cost_t"]}
+        return t["cur_obs"], t["rew_t"], t["term_t"], info
+
+    def any_alive(self):
+        """True while any shard still has alive branches (== pool.n_alive > 0 on one GPU)."""
+        if self.comm is not None and self.comm.world > 1:
+            return getattr(self, "global_alive", 1) > 0
+        return self.pool.n_alive > 0
 
     def finish_all_paths(self):
         """model_sampler.py:418-444: bootstrap-finish whatever is still alive, return diagnostics."""

@@ -319,38 +319,33 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
       f32x16 acc[NT][BT];
       init_acc_bias<NT, BT>(acc, bias_l + HID, wave * NT * 32, lane);
       const f32x4 *wp = p.wp1 + e * p.wp1_stride + (size_t)(wave * NT) * KG_H * 64;
+      // (a two-group-deep ring, mfma_layer<..., DEPTH = 2>, measured no faster: the lone-wave loss is the
+      // ~27-cycle issue cost of each global_load_dwordx4 next to the MFMAs, not exposed latency)
       mfma_layer<NT, BT>(wp, (size_t)KG_H * 64, 0, KG_H, hbuf, lane, acc);
       STAMP(4);
       activate_regs<NT, BT, ACT>(acc);   // h2 slice of this wave
-      // K of the output layer is split over the waves: wave w contributes k in [128 w, 128 w + 128) for
-      // HID = 512 ([32 w, 32 w + 32) for 128) -- its own h2 slice
-      f32x16 part[4][BT];  // o_tiles <= 4, statically indexed below
-#pragma unroll
-      for (int ot = 0; ot < 4; ++ot) {
-        if (ot < p.o_tiles) {
-#pragma unroll
-          for (int bt = 0; bt < BT; ++bt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) part[ot][bt][r] = 0.0f;
-          const f32x4 *wp2 = p.wp2 + e * p.wp2_stride + (size_t)ot * KG_H * 64;
-          mfma_from_regs<NT, BT>(wp2, wave * NT * 4, acc, lane, part[ot]);
-        }
-      }
       STAMP(5);
       __syncthreads();  // every wave has finished reading h1: hbuf becomes the reduction image
       STAMP(6);
+      // K of the output layer is split over the waves: wave w contributes k in [128 w, 128 w + 128) for
+      // HID = 512 ([32 w, 32 w + 32) for 128) -- its own h2 slice, straight from registers.  One output tile at
+      // a time keeps a single 16-register partial live.
       const int j = lane & 31, h = lane >> 5;
+      for (int ot = 0; ot < p.o_tiles; ++ot) {
+        f32x16 part[BT];
 #pragma unroll
-      for (int ot = 0; ot < 4; ++ot) {
-        if (ot < p.o_tiles) {
+        for (int bt = 0; bt < BT; ++bt)
 #pragma unroll
-          for (int bt = 0; bt < BT; ++bt)
+          for (int r = 0; r < 16; ++r) part[bt][r] = 0.0f;
+        const f32x4 *wp2 = p.wp2 + e * p.wp2_stride + (size_t)ot * KG_H * 64;
+        mfma_from_regs<NT, BT>(wp2, wave * NT * 4, acc, lane, part);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int n = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-              red[(wave * p.o_tiles * 32 + n) * RED_LD + bt * 32 + j] = part[ot][bt][r];
-            }
-        }
+        for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            red[(wave * p.o_tiles * 32 + n) * RED_LD + bt * 32 + j] = part[bt][r];
+          }
       }
     }
     __syncthreads();

@@ -25,7 +25,7 @@ __device__ __forceinline__ void mfma_block(const f32x4 (&a)[NT], const f32x4 (&b
 // ROWS == false: B operand in the T-layout (float4 [k/4][BB]).  ROWS == true: B operand in a row layout
 // [b][row_stride] of floats (k contiguous per sample); with row_stride / 4 odd (132, 36, 52, ...) the per-lane
 // 16-B reads of a wave fall on distinct banks, so the same image also serves the weight-gradient MFMAs.
-template <int NT, int BT, bool ROWS = false>
+template <int NT, int BT, bool ROWS = false, int DEPTH = 1>
 __device__ __forceinline__ void mfma_layer(const f32x4 *__restrict__ wp,
                                            size_t nt_stride, int g0, int g1,
                                            const f32x4 *lds_in, int lane,
@@ -50,6 +50,30 @@ __device__ __forceinline__ void mfma_layer(const f32x4 *__restrict__ wp,
       else b[bt] = *reinterpret_cast<const f32x4 *>(row_lane + bt * 32 * row_stride + 8 * g);
     }
   };
+  if constexpr (DEPTH == 2) {
+    // two k-groups in flight (three register sets): a lone wave per SIMD issues a block in 1024 cycles while an L2
+    // hit under load takes ~1150, so one group of lead is not enough when the partner workgroup is not computing
+    f32x4 a2[NT], b2[BT];
+    const int last = g1 - 1;
+    request(g0, a0, b0);
+    request(g0 + 1 < g1 ? g0 + 1 : last, a1, b1);
+    int g = g0;
+#pragma unroll 1
+    for (; g + 2 < g1; g += 3) {
+      request(g + 2, a2, b2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block<NT, BT>(a0, b0, acc);
+      request(g + 3 < g1 ? g + 3 : last, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block<NT, BT>(a1, b1, acc);
+      request(g + 4 < g1 ? g + 4 : last, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block<NT, BT>(a2, b2, acc);
+    }
+    if (g < g1) mfma_block<NT, BT>(a0, b0, acc);
+    if (g + 1 < g1) mfma_block<NT, BT>(a1, b1, acc);
+    return;
+  }
   request(g0, a0, b0);
   int g = g0;
 #pragma unroll 1

@@ -23,7 +23,7 @@ def _need_gpu():
 
 
 def _world(task, hidden=128, B=64, T=8, mode="uncertainty", seed=31):
-    from make_golden import build_world
+    from worlds import build_world
     from test_rollout_sampler_gpu import hip_world
     w = build_world(seed, task, hidden)
     sampler, pool = hip_world(w, task, T, mode, float("inf"), B, hidden)
@@ -94,7 +94,7 @@ def test_compute_dynamics_dkl_matches_oracle(hip_lib):
 
 def test_compute_dkl_run_diagnostics_update_real_c(hip_lib):
     _need_gpu()
-    from make_golden import make_update_batch
+    from worlds import make_update_batch
     from cmbpo_amd.cpo_policy import CPOPolicy
     D, A, n, T = 20, 6, 500, 35
     rng = np.random.default_rng(8)

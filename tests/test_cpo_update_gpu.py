@@ -32,7 +32,7 @@ def _close(got, ref, rtol=1e-3, arel=3e-5, msg=""):
 
 
 def _setup(D, A, n, seed, cost_p=0.3, cadv_scale=1.0, T=35):
-    from make_golden import make_update_batch
+    from worlds import make_update_batch
     from cmbpo_amd.cpo_update import PolicyOps
     rng = np.random.default_rng(seed)
     params, batch = make_update_batch(rng, n, D, A, 128, cost_p, cadv_scale, T)
@@ -103,7 +103,7 @@ SCENARIOS = [   # name, cost_p, cadv_scale, cost_lim, constrained, real_cost, se
 @pytest.mark.parametrize("name,cost_p,cadv_scale,cost_lim,constrained,real_cost,seed", SCENARIOS)
 def test_update_policy_matches_oracle(hip_lib, name, cost_p, cadv_scale, cost_lim, constrained, real_cost, seed):
     _need_gpu()
-    from make_golden import make_update_batch
+    from worlds import make_update_batch
     from cmbpo_amd.cpo_policy import CPOPolicy
     D, A, n, T = 29, 8, 4000, 35
     rng = np.random.default_rng(seed)

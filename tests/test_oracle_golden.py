@@ -102,7 +102,7 @@ TRACES = ["g5_trace_ant_unc", "g5_trace_ant_term", "g5_trace_hcs_sched", "g5_tra
 def test_g5_rollout_oracle_matches_reference_trace(name):
     import sys
     sys.path.insert(0, GOLD)
-    from make_golden import build_world
+    from worlds import build_world
     g = _load(name)
     orc, alive, totals, ratios, res, diag = replay_trace(g, build_world)
     np.testing.assert_array_equal(alive, g["alive"])                    # masks per step: bit-exact
@@ -168,7 +168,7 @@ def test_oracle_graph_analytic_cross_checks():
     import sys
     import torch
     sys.path.insert(0, GOLD)
-    from make_golden import make_update_batch
+    from worlds import make_update_batch
     from oracle import refupdate
     rng = np.random.default_rng(3)
     D, A, H, n, T = 5, 2, 16, 64, 10

@@ -70,7 +70,7 @@ def _need_gpu():
                                   "g5_trace_hopper_budget"])
 def test_hip_sampler_reproduces_reference_trace(hip_lib, name):
     _need_gpu()
-    from make_golden import build_world
+    from worlds import build_world
     g = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
     task, B, T, hidden = str(g["task"]), int(g["B"]), int(g["T"]), int(g["hidden"])
     w = build_world(int(g["seed"]), task, hidden, out_scale=float(g["out_scale"]), q_boost=float(g["q_boost"]))
@@ -121,7 +121,7 @@ def _oracle(w, task, T, mode, lim):
 ])
 def test_hip_sampler_matches_oracle_on_fresh_seeds(hip_lib, task, B, T, hidden, budget):
     _need_gpu()
-    from make_golden import build_world
+    from worlds import build_world
     from cmbpo_amd import synthetic
     seed = 1234
     w = build_world(seed, task, hidden, q_boost=1.2 if task == "AntSafe-v2" else 0.0)

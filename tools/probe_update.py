@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np, torch
 import cmbpo_amd
 from cmbpo_amd.cpo_policy import CPOPolicy
-from make_golden import make_update_batch
+from worlds import make_update_batch
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 constrained = (sys.argv[2] != "0") if len(sys.argv) > 2 else True

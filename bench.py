@@ -271,7 +271,7 @@ def main():
         out["cpo_update"] = {"unit": "ms", "n_50k": n50, "ms_50k": upd_ms_50k, "n_full": n_full,
                              "ms_full": upd_ms_full, "optim_case": int(upd_info["OptimCase"]),
                              "hvps": 22 if upd_info["OptimCase"] != 4 else 11, "per_rank": True}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # the CPU baseline is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(w, task, seconds=args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             out["cpu_baseline"]["cpo_update_ms_50k"] = cpu_update_baseline(w, res, n50)

@@ -109,6 +109,21 @@ SIGNATURES.update({
     "cmbpo_adv_normalize": (_i, [_i, _p, _p, _p, _p]),
 })
 
+# ensemble training (csrc/ens_train.hip)
+SIGNATURES.update({
+    "cmbpo_trainer_create": (_i, [C.POINTER(_p), _p, _i, C.c_float, _p]),
+    "cmbpo_trainer_destroy": (None, [_p]),
+    "cmbpo_trainer_set_weights": (_i, [_p] * 8),
+    "cmbpo_trainer_get_weights": (_i, [_p] * 8),
+    "cmbpo_trainer_reset_optimizer": (_i, [_p, _p]),
+    "cmbpo_trainer_get_moments": (_i, [_p, _i] + [_p] * 7),
+    "cmbpo_trainer_set_moments": (_i, [_p, _i] + [_p] * 6 + [C.c_long, _p]),
+    "cmbpo_mlp_set_scalers": (_i, [_p] * 6),
+    "cmbpo_trainer_step": (_i, [_p, _p, _i, _p, _i, _p, _i, _i, _p]),
+    "cmbpo_trainer_losses": (_i, [_p, _p, _i, _p, _i, _p, _i, _i, _p, _p]),
+    "cmbpo_trainer_steps_done": (C.c_long, [_p]),
+})
+
 _lib = None
 
 

@@ -22,6 +22,7 @@
 // Hidden layers split N over the 4 waves, the (narrow) output layer splits K
 // over the 4 waves and reduces through LDS.
 #include "common.h"
+#include "ens_mlp_internal.h"
 #include "mfma_tile.h"
 
 #include <math.h>
@@ -48,37 +49,6 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
 
-struct MlpKernelArgs {
-  // packed weights, float4 units
-  const f32x4 *wp0, *wp1, *wp2;
-  size_t wp0_stride, wp1_stride, wp2_stride;  // per member, in float4
-  const float *b0, *b1, *b2;                  // [E][HID],[E][HID],[E][o_pad]
-  const float *in_mu, *in_sig;                // [in_dim] or nullptr; sig = max(sqrt(var), 1e-2)
-  const float *out_mu, *out_sig, *out_lsig2;  // [out_dim] or nullptr; lsig2 = 2 log(sig)
-  const float *log_std;                       // [out_dim] (policy head)
-  int ensemble, e_chunk;
-  int in_dim, in_pad;  // in_pad multiple of 8
-  int o_width, o_tiles, out_dim;
-  // inputs
-  const float *obs;
-  int obs_dim;
-  const float *act;
-  int act_dim;
-  const float *eps;
-  const int32_t *row_idx;
-  const int32_t *n_rows_dev;
-  int n_rows;
-  int ld_rows;
-  // outputs
-  float *out0;  // mean | predict-mean | pi
-  float *out1;  // var  |              | logp
-  float *out2;  //                     | mu
-  float *out3;  //                     | log_std broadcast
-  unsigned long long *stamps;  // diagnostic builds only
-  int stagger_sleeps;          // s_sleep(127) repetitions for the second dispatch batch (0 = off)
-  int tiles, n_items, n_cu;    // persistent grid: items = member chunks x row tiles, member-major
-  int *work_counter;           // device counter for dynamic item claiming (nullptr: static striding)
-};
 
 template <int ACT>
 __device__ __forceinline__ float activate(float x) {
@@ -89,6 +59,14 @@ __device__ __forceinline__ float activate(float x) {
   } else {
     return tanhf(x);
   }
+}
+
+// swish and its derivative from one sigmoid: h = z s, dh/dz = s (1 + z (1 - s)).  Training keeps the IEEE divide:
+// the exported activations are the operands of the weight gradients.
+__device__ __forceinline__ void swish_with_grad(float z, float &h, float &g) {
+  const float sg = 1.0f / (1.0f + __expf(-z));
+  h = z * sg;
+  g = sg * (1.0f + z * (1.0f - sg));
 }
 
 // Accumulators start from the bias (read from LDS as the same float4 groups the tile rows form), so the
@@ -127,6 +105,42 @@ __device__ __forceinline__ void store_hidden(const f32x16 (&acc)[NT][BT],
 #pragma unroll
         for (int s = 0; s < 4; ++s) v[s] = activate<ACT>(acc[t][bt][4 * q + s]);
         lds_out[(n >> 2) * BB + bt * 32 + j] = v;
+      }
+    }
+  }
+}
+
+// Training forward: as store_hidden / activate_regs (swish), and the activation h and its derivative g of the
+// wave's [n-slice x BB rows] tile go to the export arrays [row][HID] as float4 groups of four consecutive n.
+// `grow` = first export row of the tile (member offset included), rows at or beyond `n_valid` are not written.
+template <int NT, int BT, int HID, bool TO_LDS>
+__device__ __forceinline__ void hidden_train(f32x16 (&acc)[NT][BT], int n_base, f32x4 *lds_out, int lane,
+                                             float *__restrict__ eh, float *__restrict__ eg, size_t grow, int n_valid) {
+  constexpr int BB = 32 * BT;
+  const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n0 = n_base + t * 32;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + 8 * q + 4 * h;
+#pragma unroll
+      for (int bt = 0; bt < BT; ++bt) {
+        f32x4 hv, gv;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          float a, b;
+          swish_with_grad(acc[t][bt][4 * q + s], a, b);
+          hv[s] = a; gv[s] = b;
+          acc[t][bt][4 * q + s] = a;
+        }
+        if constexpr (TO_LDS) lds_out[(n >> 2) * BB + bt * 32 + j] = hv;
+        const int b = bt * 32 + j;
+        if (eh && b < n_valid) {
+          const size_t o = (grow + b) * HID + n;
+          *reinterpret_cast<f32x4 *>(eh + o) = hv;
+          *reinterpret_cast<f32x4 *>(eg + o) = gv;
+        }
       }
     }
   }
@@ -244,7 +258,12 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
     for (int rb = 0; rb < BT; ++rb) {
       const int b = (tid >> 3) + 32 * rb;
       int r = row0 + b;
-      r = (r < n_rows) ? (p.row_idx ? p.row_idx[r] : r) : -1;
+      if constexpr (HEAD == CMBPO_HEAD_TRAIN) {
+        // per-member bootstrap rows: member (= chunk, e_chunk is 1) reads its own index list
+        r = (r < n_rows) ? (p.row_idx ? p.row_idx[(size_t)chunk * p.row_idx_stride + r] : r) : -1;
+      } else {
+        r = (r < n_rows) ? (p.row_idx ? p.row_idx[r] : r) : -1;
+      }
       if (c == 0) rows[b] = r;
       for (int k0 = 0; k0 < p.in_pad; k0 += 64) {
         float v[8], mu[8], sig[8];
@@ -268,6 +287,9 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
               x = (x - mu[u]) / sig[u];
             }
             xf[((k >> 2) * BB + b) * 4 + (k & 3)] = x;   // k >= in_dim: zero padding
+            if constexpr (HEAD == CMBPO_HEAD_TRAIN) {
+              if (p.tr_x && r >= 0) p.tr_x[((size_t)chunk * n_rows + row0 + b) * p.in_pad + k] = x;
+            }
           }
         }
       }
@@ -310,7 +332,11 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
       const f32x4 *wp = p.wp0 + e * p.wp0_stride + (size_t)(wave * NT) * kg0 * 64;
       mfma_layer<NT, BT>(wp, (size_t)kg0 * 64, 0, kg0, xbuf, lane, acc);
       STAMP(2);
-      store_hidden<NT, BT, ACT>(acc, wave * NT * 32, hbuf, lane);
+      if constexpr (HEAD == CMBPO_HEAD_TRAIN)
+        hidden_train<NT, BT, HID, true>(acc, wave * NT * 32, hbuf, lane, p.tr_h1, p.tr_g1,
+                                        (size_t)e * n_rows + row0, n_rows - row0);
+      else
+        store_hidden<NT, BT, ACT>(acc, wave * NT * 32, hbuf, lane);
     }
     __syncthreads();
     STAMP(3);
@@ -323,7 +349,11 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
       // ~27-cycle issue cost of each global_load_dwordx4 next to the MFMAs, not exposed latency)
       mfma_layer<NT, BT>(wp, (size_t)KG_H * 64, 0, KG_H, hbuf, lane, acc);
       STAMP(4);
-      activate_regs<NT, BT, ACT>(acc);   // h2 slice of this wave
+      if constexpr (HEAD == CMBPO_HEAD_TRAIN)
+        hidden_train<NT, BT, HID, false>(acc, wave * NT * 32, nullptr, lane, p.tr_h2, p.tr_g2,
+                                         (size_t)e * n_rows + row0, n_rows - row0);
+      else
+        activate_regs<NT, BT, ACT>(acc);   // h2 slice of this wave
       STAMP(5);
       __syncthreads();  // every wave has finished reading h1: hbuf becomes the reduction image
       STAMP(6);
@@ -373,6 +403,14 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
         const size_t o = ((size_t)e * p.ld_rows + r) * out + n;
         p.out0[o] = m;
         p.out1[o] = __expf(lv);
+      }
+    } else if constexpr (HEAD == CMBPO_HEAD_TRAIN) {
+      // raw network output (no output scaler, no exp): models/pens/pe.py:803-812 with ret_log_var
+      const int ow = p.o_width;
+      for (int i = tid; i < BB * ow; i += kThreads) {
+        const int b = i / ow, n = i - b * ow;
+        if (rows[b] < 0) continue;
+        p.out0[((size_t)e * n_rows + row0 + b) * ow + n] = reduced(b, n);
       }
     } else if constexpr (HEAD == CMBPO_HEAD_DETMEAN) {
       const int out = p.out_dim;
@@ -443,16 +481,6 @@ void pack_weights(const float *w, int K, int N, int k_pad, int n_tiles, float *d
 
 }  // namespace
 
-struct cmbpo_mlp {
-  int ensemble, in_dim, in_pad, hidden, o_width, o_tiles, out_dim, act, head;
-  bool loaded, has_in_scaler, has_out_scaler;
-  float *d_blob;  // one allocation holding everything below
-  size_t blob_floats;
-  // offsets (in floats) into the blob
-  size_t off_wp0, off_wp1, off_wp2, off_b0, off_b1, off_b2;
-  size_t off_in_mu, off_in_var, off_out_mu, off_out_var, off_out_lsig2, off_log_std;   // *_var hold sigma
-  std::vector<float> h_blob;
-};
 
 extern "C" int cmbpo_mlp_create(cmbpo_mlp_t **out, int ensemble, int in_dim, int hidden,
                                 int out_width, int activation, int head) {
@@ -613,7 +641,8 @@ int g_block_rows = 32;  // 32 (2 workgroups / CU) or 64 (1 workgroup / CU)
 int g_stagger = 10;     // x s_sleep(127) (~8k cycles each) for the second dispatch batch
 int g_lds_pad = 0;      // diagnostic: extra dynamic LDS bytes (forces one workgroup per CU)
 
-int launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
+int launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s, int head_override = -1) {
+  const int head = head_override >= 0 ? head_override : m->head;
   const float *blob = m->d_blob;
   const int E = m->ensemble, H = m->hidden;
   a.wp0 = reinterpret_cast<const f32x4 *>(blob + m->off_wp0);
@@ -632,14 +661,14 @@ int launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
 #ifdef CMBPO_STAMPS
   a.stamps = g_stamps;
 #endif
-  a.stagger_sleeps = (H == 512) ? g_stagger : 0;
+  a.stagger_sleeps = (H == 512 && head != CMBPO_HEAD_TRAIN) ? g_stagger : 0;
   a.ensemble = E;
-  a.e_chunk = (m->head == CMBPO_HEAD_PROB) ? 1 : E;
+  a.e_chunk = (head == CMBPO_HEAD_PROB || head == CMBPO_HEAD_TRAIN) ? 1 : E;
   a.in_dim = m->in_dim; a.in_pad = m->in_pad;
   a.o_width = m->o_width; a.o_tiles = m->o_tiles; a.out_dim = m->out_dim;
   if (a.n_rows <= 0) return CMBPO_OK;
 
-  const int BT = (H == 512 && g_block_rows == 64) ? 2 : 1;
+  const int BT = (H == 512 && g_block_rows == 64 && head != CMBPO_HEAD_TRAIN) ? 2 : 1;
   const int BB = 32 * BT;
   const int tiles = cmbpo_ceil_div(a.n_rows, BB);
   const int grid_y = cmbpo_ceil_div(E, a.e_chunk);
@@ -650,23 +679,30 @@ int launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
 
 #define CMBPO_LAUNCH(HID_, BT_, ACT_, HEAD_) \
   return launch_one<HID_, BT_, ACT_, HEAD_>(a, tiles, grid_y, lds + g_lds_pad, s)
-  if (m->head == CMBPO_HEAD_PROB && m->act == CMBPO_ACT_SWISH) {
+  if (head == CMBPO_HEAD_TRAIN && m->act == CMBPO_ACT_SWISH) {
+    if (H == 512) CMBPO_LAUNCH(512, 1, CMBPO_ACT_SWISH, CMBPO_HEAD_TRAIN);
+    if (H == 128) CMBPO_LAUNCH(128, 1, CMBPO_ACT_SWISH, CMBPO_HEAD_TRAIN);
+  } else if (head == CMBPO_HEAD_PROB && m->act == CMBPO_ACT_SWISH) {
     if (H == 512 && BT == 1) CMBPO_LAUNCH(512, 1, CMBPO_ACT_SWISH, CMBPO_HEAD_PROB);
     if (H == 512 && BT == 2) CMBPO_LAUNCH(512, 2, CMBPO_ACT_SWISH, CMBPO_HEAD_PROB);
     if (H == 128) CMBPO_LAUNCH(128, 1, CMBPO_ACT_SWISH, CMBPO_HEAD_PROB);
-  } else if (m->head == CMBPO_HEAD_DETMEAN && m->act == CMBPO_ACT_SWISH) {
+  } else if (head == CMBPO_HEAD_DETMEAN && m->act == CMBPO_ACT_SWISH) {
     if (H == 128) CMBPO_LAUNCH(128, 1, CMBPO_ACT_SWISH, CMBPO_HEAD_DETMEAN);
     if (H == 512) CMBPO_LAUNCH(512, 1, CMBPO_ACT_SWISH, CMBPO_HEAD_DETMEAN);
-  } else if (m->head == CMBPO_HEAD_GAUSS_PI && m->act == CMBPO_ACT_TANH) {
+  } else if (head == CMBPO_HEAD_GAUSS_PI && m->act == CMBPO_ACT_TANH) {
     if (H == 128) CMBPO_LAUNCH(128, 1, CMBPO_ACT_TANH, CMBPO_HEAD_GAUSS_PI);
     if (H == 512) CMBPO_LAUNCH(512, 1, CMBPO_ACT_TANH, CMBPO_HEAD_GAUSS_PI);
   }
 #undef CMBPO_LAUNCH
-  cmbpo_set_error("ens_mlp: no kernel for hidden=%d act=%d head=%d", H, m->act, m->head);
+  cmbpo_set_error("ens_mlp: no kernel for hidden=%d act=%d head=%d", H, m->act, head);
   return CMBPO_EINVAL;
 }
 
 }  // namespace
+
+int cmbpo_internal_launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s, int head_override) {
+  return launch_mlp(m, a, s, head_override);
+}
 
 extern "C" int cmbpo_set_dispatch_mode(int mode) {
   CMBPO_REQUIRE(mode >= 0 && mode <= 2, "cmbpo_set_dispatch_mode: 0 (per-item), 1 (persistent static), 2 (persistent dynamic)");

@@ -1,0 +1,60 @@
+// Internal (not part of the C-ABI): shared between ens_mlp.hip and ens_train.hip.
+#pragma once
+#include "common.h"
+
+#include <vector>
+
+#define CMBPO_HEAD_TRAIN 3   // raw outputs + exported activations, per-member row gather (training forward)
+
+struct MlpKernelArgs {
+  // packed weights, float4 units
+  const f32x4 *wp0, *wp1, *wp2;
+  size_t wp0_stride, wp1_stride, wp2_stride;  // per member, in float4
+  const float *b0, *b1, *b2;                  // [E][HID],[E][HID],[E][o_pad]
+  const float *in_mu, *in_sig;                // [in_dim] or nullptr; sig = max(sqrt(var), 1e-2)
+  const float *out_mu, *out_sig, *out_lsig2;  // [out_dim] or nullptr; lsig2 = 2 log(sig)
+  const float *log_std;                       // [out_dim] (policy head)
+  int ensemble, e_chunk;
+  int in_dim, in_pad;  // in_pad multiple of 8
+  int o_width, o_tiles, out_dim;
+  // inputs
+  const float *obs;
+  int obs_dim;
+  const float *act;
+  int act_dim;
+  const float *eps;
+  const int32_t *row_idx;
+  const int32_t *n_rows_dev;
+  int n_rows;
+  int ld_rows;
+  // outputs
+  float *out0;  // mean | predict-mean | pi
+  float *out1;  // var  |              | logp
+  float *out2;  //                     | mu
+  float *out3;  //                     | log_std broadcast
+  unsigned long long *stamps;  // diagnostic builds only
+  int stagger_sleeps;          // s_sleep(127) repetitions for the second dispatch batch (0 = off)
+  int tiles, n_items, n_cu;    // persistent grid: items = member chunks x row tiles, member-major
+  int *work_counter;           // device counter for dynamic item claiming (nullptr: static striding)
+  // training forward (HEAD_TRAIN): rows are gathered through a per-member index list and every intermediate
+  // the backward pass needs is exported, indexed [member][batch row][...]
+  int row_idx_stride;          // elements between the index lists of consecutive members
+  float *tr_x;                 // [E][n_rows][in_pad]  scaled inputs
+  float *tr_h1, *tr_g1;        // [E][n_rows][HID]     swish(z1), swish'(z1)
+  float *tr_h2, *tr_g2;        // [E][n_rows][HID]
+};
+
+struct cmbpo_mlp {
+  int ensemble, in_dim, in_pad, hidden, o_width, o_tiles, out_dim, act, head;
+  bool loaded, has_in_scaler, has_out_scaler;
+  float *d_blob;  // one allocation holding everything below
+  size_t blob_floats;
+  // offsets (in floats) into the blob
+  size_t off_wp0, off_wp1, off_wp2, off_b0, off_b1, off_b2;
+  size_t off_in_mu, off_in_var, off_out_mu, off_out_var, off_out_lsig2, off_log_std;   // *_var hold sigma
+  std::vector<float> h_blob;
+};
+
+// fills the weight / scaler pointers of `a` from the handle and launches the kernel matching (hidden, act, head);
+// head_override >= 0 replaces the handle's head (HEAD_TRAIN on a PROB / DETMEAN handle).
+int cmbpo_internal_launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s, int head_override);

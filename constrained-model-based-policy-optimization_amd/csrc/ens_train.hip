@@ -1,0 +1,836 @@
+// Ensemble training step for gfx950: the TensorFlow train_op of the reference's
+// probabilistic ensemble, as hand-written kernels over device-resident data.
+//
+// Replaces
+//   models/pens/pe.py:252-274,312-315   train_loss = sum_e loss_e + sum_l decay_l * l2_loss(W_l); Adam apply
+//   models/pens/pe.py:921-973           _mspe_loss (dynamics ensemble, loss 'MSPE')
+//   models/pens/pe.py:840-919           _nll_loss(inc_var_loss=False) (critics, loss 'MSE'; also `self.loss`,
+//                                       the per-member holdout loss that ranks the elites)
+//   models/pens/fc.py:74-95,167-168     batched per-member matmul + swish, weight decay
+//   models/pens/pe.py:543-551           inputs[batch_idxs]: the per-member bootstrap gather (done in the kernel)
+//
+// One step = training forward (ens_mlp_kernel<HEAD_TRAIN>: raw outputs + exported activations and swish
+// derivatives) -> loss sums -> d(loss)/d(output) -> fused backward chain (two transposed-weight GEMMs, the
+// delta of the middle layer never leaves the CU un-multiplied) -> three weight-gradient GEMMs with the batch as
+// the K dimension (fp32 MFMA, split-K partials, no atomics: the step is bitwise reproducible) -> Adam with the
+// TensorFlow update rule, which also re-packs the new weights into the MFMA layouts the forward / backward
+// kernels read (the master copy stays row-major for checkpoints).
+#include "common.h"
+#include "ens_mlp_internal.h"
+#include "mfma_tile.h"
+
+#include <math.h>
+#include <new>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// loss: per-member sums, then d(train_loss)/d(raw output)
+// ------------------------------------------------------------------------------------------------------------
+struct LossArgs {
+  const float *o;          // [E][B][O] raw network output
+  const float *targets;    // [N][D]
+  const int32_t *idx;      // [E][idx_stride] rows of `targets` (nullptr: row b)
+  int idx_stride;
+  const float *out_mu, *out_sig;   // output scaler (nullptr: identity)
+  int E, B, O, D, OPk, prob;
+  double *sums;            // [3][E]: sum (mean - t)^2 | sum (var - mse)^2 | sum log_var^2
+  float *d3;               // [E][B][OPk]
+};
+
+__device__ __forceinline__ float scaled_target(const LossArgs &p, int e, int b, int d) {
+  const int row = p.idx ? p.idx[(size_t)e * p.idx_stride + b] : b;
+  float t = p.targets[(size_t)row * p.D + d];
+  if (p.out_mu) t = (t - p.out_mu[d]) / p.out_sig[d];   // TensorStandardScaler.transform, models/pens/utils.py:156
+  return t;
+}
+
+__global__ __launch_bounds__(kThreads) void loss_sums_kernel(const LossArgs p) {
+  const int e = blockIdx.y;
+  double s_mse = 0.0, s_vl = 0.0, s_lv = 0.0;
+  const int n = p.B * p.D;
+  for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+    const int b = i / p.D, d = i - b * p.D;
+    const float *orow = p.o + ((size_t)e * p.B + b) * p.O;
+    const float diff = orow[d] - scaled_target(p, e, b, d);
+    const float mse = diff * diff;
+    s_mse += (double)mse;
+    if (p.prob) {
+      const float lv = orow[p.D + d];
+      const float dv = expf(lv) - mse;
+      s_vl += (double)(dv * dv);
+      s_lv += (double)(lv * lv);
+    }
+  }
+  __shared__ double sm[3][kThreads / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  s_mse = wave_sum(s_mse); s_vl = wave_sum(s_vl); s_lv = wave_sum(s_lv);
+  if (lane == 0) { sm[0][w] = s_mse; sm[1][w] = s_vl; sm[2][w] = s_lv; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double t = 0.0;
+    for (int i = 0; i < kThreads / 64; ++i) t += sm[threadIdx.x][i];
+    atomicAdd(p.sums + (size_t)threadIdx.x * p.E + e, t);
+  }
+}
+
+// MSPE (pe.py:921-973): total_e = mean (m - t)^2 + ratio * mean (var - sg(mse))^2 + 0.05 * mean_all lv^2, with
+// ratio = 0.05 * mean_all(mse) / mean_all((var - mse)^2) a constant of the step; train_loss = sum_e total_e, so the
+// regulariser (a scalar broadcast onto every member) counts E times.
+// MSE (pe.py:911-919): total_e = mean 0.5 (o - t)^2.
+__global__ __launch_bounds__(kThreads) void loss_delta_kernel(const LossArgs p) {
+  const size_t total = (size_t)p.E * p.B * p.OPk;
+  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= total) return;
+  const int n = (int)(i % p.OPk);
+  const size_t eb = i / p.OPk;
+  const int b = (int)(eb % p.B), e = (int)(eb / p.B);
+  const float inv_bd = 1.0f / ((float)p.B * (float)p.D);
+  float d = 0.0f;
+  if (n < p.O) {
+    const float *orow = p.o + ((size_t)e * p.B + b) * p.O;
+    if (!p.prob) {
+      d = (orow[n] - scaled_target(p, e, b, n)) * inv_bd;
+    } else if (n < p.D) {
+      d = 2.0f * (orow[n] - scaled_target(p, e, b, n)) * inv_bd;
+    } else {
+      double tm = 0.0, tv = 0.0;
+      for (int k = 0; k < p.E; ++k) { tm += p.sums[k]; tv += p.sums[p.E + k]; }
+      const float ratio = (float)(0.05 * tm / tv);
+      const int dd = n - p.D;
+      const float diff = orow[dd] - scaled_target(p, e, b, dd);
+      const float lv = orow[n], var = expf(lv);
+      d = (2.0f * ratio * (var - diff * diff) * var + 0.1f * lv) * inv_bd;
+    }
+  }
+  p.d3[i] = d;
+}
+
+// `self.loss` of the reference for n rows seen so far: per-member 0.5 * mean (mean - t)^2
+__global__ void loss_finalize_kernel(const double *sums, int E, double inv_count, float *out) {
+  const int e = threadIdx.x;
+  if (e < E) out[e] = (float)(0.5 * sums[e] * inv_count);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward chain:  d2 = (d3 W2^T) * g2 ;  d1 = (d2 W1^T) * g1      (g = swish'(z) exported by the forward)
+// Same transposed-GEMM formulation as the forward (see ens_mlp.hip): rows of the batch on the MFMA columns, the
+// transposed weights packed [n-tile][k-group][lane][4], the d2 tile handed from the first GEMM to the second
+// through LDS.  One workgroup = 32 batch rows of one member.
+// ------------------------------------------------------------------------------------------------------------
+struct BwdArgs {
+  const f32x4 *wpb2, *wpb1;
+  size_t wpb2_stride, wpb1_stride;   // per member, float4 units
+  const float *d3, *g2, *g1;
+  float *d2, *d1;
+  int B, OPk;
+};
+
+template <int HID>
+__global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdArgs p) {
+  constexpr int BB = 32, NT = HID / 128, KG_H = HID / 8;
+  extern __shared__ f32x4 smem[];
+  f32x4 *hbuf = smem;                    // d2 tile, T-layout [HID/4][BB]
+  f32x4 *xbuf = smem + HID / 4 * BB;     // d3 tile, T-layout [OPk/4][BB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int e = blockIdx.y, row0 = blockIdx.x * BB;
+  const int kgo = p.OPk / 8;
+  {
+    float *xf = reinterpret_cast<float *>(xbuf);
+    for (int i = tid; i < BB * p.OPk; i += kThreads) {
+      const int b = i / p.OPk, k = i - b * p.OPk;
+      float v = 0.0f;
+      if (row0 + b < p.B) v = p.d3[((size_t)e * p.B + row0 + b) * p.OPk + k];
+      xf[((k >> 2) * BB + b) * 4 + (k & 3)] = v;
+    }
+  }
+  const int j = lane & 31, h = lane >> 5;
+  const bool valid = row0 + j < p.B;
+  const size_t grow = ((size_t)e * p.B + row0 + j) * HID;
+  const int n_base = wave * NT * 32;
+  f32x4 gq[NT][4];
+  auto load_g = [&](const float *g) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n_base + t * 32 + 8 * q + 4 * h;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (valid) v = *reinterpret_cast<const f32x4 *>(g + grow + n);
+        gq[t][q] = v;
+      }
+  };
+  f32x16 acc[NT][1];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][0][r] = 0.0f;
+  };
+  load_g(p.g2);      // in flight under the first GEMM
+  zero_acc();
+  __syncthreads();
+  mfma_layer<NT, 1>(p.wpb2 + e * p.wpb2_stride + (size_t)(wave * NT) * kgo * 64, (size_t)kgo * 64, 0, kgo, xbuf, lane, acc);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n_base + t * 32 + 8 * q + 4 * h;
+      f32x4 v;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) v[s] = acc[t][0][4 * q + s] * gq[t][q][s];
+      hbuf[(n >> 2) * BB + j] = v;
+      if (valid) *reinterpret_cast<f32x4 *>(p.d2 + grow + n) = v;
+    }
+  load_g(p.g1);
+  zero_acc();
+  __syncthreads();
+  mfma_layer<NT, 1>(p.wpb1 + e * p.wpb1_stride + (size_t)(wave * NT) * KG_H * 64, (size_t)KG_H * 64, 0, KG_H, hbuf, lane, acc);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n_base + t * 32 + 8 * q + 4 * h;
+      f32x4 v;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) v[s] = acc[t][0][4 * q + s] * gq[t][q][s];
+      if (valid) *reinterpret_cast<f32x4 *>(p.d1 + grow + n) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// weight gradients:  C[e][m][n] = sum_b A[e][b][m] * Bm[e][b][n]      (K of the GEMM = the batch)
+// Both operands are read straight from their [row][feature] arrays: a lane's 16-B (A) / 8-B (Bm) load of one
+// batch row feeds 4 / 2 MFMA tiles whose rows / columns are interleaved (tile mi holds m0 + 4 i + mi), so every
+// global load is a contiguous 512-B / 256-B run per batch row and no operand is staged or transposed.
+// Wave tile 128 x 64, the 4 waves of a workgroup split the workgroup's batch range and reduce through LDS; the
+// grid's K split writes partial sums that the Adam kernel adds in a fixed order.
+// ------------------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float *A; int lda;
+  const float *Bm; int ldb;
+  float *out;                  // [ks][E][out_member]
+  size_t out_member, out_part;
+  int ldc, transposed, n_out;  // C[m][n] -> out[m * ldc + n] (transposed: out[n * ldc + m]), n < n_out
+  int B, rows_per_wg, n_tiles;
+};
+
+__global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(const WgradArgs p) {
+  extern __shared__ float red[];   // [2][128][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int mt = blockIdx.x / p.n_tiles, nt = blockIdx.x - mt * p.n_tiles;
+  const int e = blockIdx.z;
+  const int m0 = mt * 128, n0 = nt * 64;
+  const int rpw = p.rows_per_wg / 4;
+  const int start = blockIdx.y * p.rows_per_wg + wave * rpw;
+  const int end = min(start + rpw, p.B);
+  const float *ap = p.A + (size_t)e * p.B * p.lda + m0 + 4 * i;
+  const float *bp = p.Bm + (size_t)e * p.B * p.ldb + n0 + 2 * i;
+  const bool bmask = n0 + 2 * i < p.ldb;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+  // Software pipeline as in mfma_layer: the 8 batch rows of the next block are requested (ping-pong register
+  // sets) before the 32 MFMAs of the current one.  Lanes whose columns lie beyond ldb read a valid dummy address:
+  // an MFMA column only depends on its own lane's B value and those columns are never stored.
+  if (start < end) {
+    const float *bp_safe = bmask ? bp : p.Bm;
+    auto request = [&](int r, f32x4 (&a)[4], float2 (&b)[4]) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t row = (size_t)(r + 2 * u + h);
+        a[u] = *reinterpret_cast<const f32x4 *>(ap + row * p.lda);
+        b[u] = *reinterpret_cast<const float2 *>(bp_safe + row * p.ldb);
+      }
+    };
+    auto block = [&](const f32x4 (&a)[4], const float2 (&b)[4]) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][mi], b[u].x, acc[mi][0], 0, 0, 0);
+          acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][mi], b[u].y, acc[mi][1], 0, 0, 0);
+        }
+    };
+    f32x4 a0[4], a1[4];
+    float2 b0[4], b1[4];
+    const int full_end = start + ((end - start) & ~7);
+    int r = start;
+    if (r < full_end) {
+      request(r, a0, b0);
+#pragma unroll 1
+      for (; r + 8 < full_end; r += 16) {
+        request(r + 8, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        block(a0, b0);
+        request(r + 16 < full_end ? r + 16 : r + 8, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        block(a1, b1);
+      }
+      if (r < full_end) block(a0, b0);
+    }
+    if (full_end < end) {   // ragged tail (batch not a multiple of 8 rows per wave): masked, not pipelined
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = full_end + 2 * u + h;
+        a0[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        b0[u] = float2{0.0f, 0.0f};
+        if (row < end) {
+          a0[u] = *reinterpret_cast<const f32x4 *>(ap + (size_t)row * p.lda);
+          b0[u] = *reinterpret_cast<const float2 *>(bp_safe + (size_t)row * p.ldb);
+        }
+      }
+      block(a0, b0);
+    }
+  }
+
+  auto spill = [&](int slot) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((slot * 128) + (mi * 2 + ni) * 16 + r) * 64 + lane] = acc[mi][ni][r];
+  };
+  auto absorb = [&](int slot) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] += red[((slot * 128) + (mi * 2 + ni) * 16 + r) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);   // one tile of LDS reads in flight at a time (register budget)
+      }
+  };
+  if (wave >= 2) spill(wave - 2);
+  __syncthreads();
+  if (wave < 2) absorb(wave);
+  __syncthreads();
+  if (wave == 1) spill(0);
+  __syncthreads();
+  if (wave != 0) return;
+  absorb(0);
+
+  float *out = p.out + (size_t)blockIdx.y * p.out_part + (size_t)e * p.out_member;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int irow = (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (!p.transposed) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + 4 * irow + mi;
+        const int n = n0 + 2 * i;
+        float *dst = out + (size_t)m * p.ldc + n;
+        if (n + 1 < p.n_out) {
+          if ((p.ldc & 1) == 0) *reinterpret_cast<float2 *>(dst) = float2{acc[mi][0][r], acc[mi][1][r]};
+          else { dst[0] = acc[mi][0][r]; dst[1] = acc[mi][1][r]; }
+        } else if (n < p.n_out) {
+          dst[0] = acc[mi][0][r];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int n = n0 + 2 * i + ni;
+        if (n < p.n_out)
+          *reinterpret_cast<f32x4 *>(out + (size_t)n * p.ldc + m0 + 4 * irow) =
+              f32x4{acc[0][ni][r], acc[1][ni][r], acc[2][ni][r], acc[3][ni][r]};
+      }
+    }
+  }
+}
+
+// bias gradients: column sums of a delta array, fixed summation order
+__global__ __launch_bounds__(kThreads) void colsum_kernel(const float *y, int ld, int n_cols, int B, float *out, int out_ld) {
+  __shared__ float sm[4][64];
+  const int e = blockIdx.y;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  float s = 0.0f;
+  if (c < n_cols) {
+    const float *col = y + (size_t)e * B * ld + c;
+    for (int b = rg; b < B; b += 4) s += col[(size_t)b * ld];
+  }
+  sm[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && c < n_cols) out[(size_t)e * out_ld + c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Adam (tf.train.AdamOptimizer: m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); w -= lr_t m / (sqrt(v) + eps)) and
+// re-packing of the updated weight into the forward ([n-tile][k-group][lane][4] of W) and backward (same layout
+// of W^T) MFMA images.
+// ------------------------------------------------------------------------------------------------------------
+struct AdamWArgs {
+  float *W, *m, *v;
+  const float *parts; int n_parts; size_t part_stride;
+  float decay;
+  int E, K, N;
+  float *fwd; int f_kg; size_t f_stride;   // forward pack: k-groups per n-tile, floats per member
+  float *bwd; int b_kg; size_t b_stride;   // backward pack (nullptr for the first layer)
+  float lr_t, b1, b2, eps;
+  int apply;                               // 0: pack only (weights loaded from the host)
+};
+
+__device__ __forceinline__ size_t pack_index(int k, int n, int kg) {
+  return ((((size_t)(n >> 5) * kg + (k >> 3)) * 64 + ((k >> 2) & 1) * 32 + (n & 31)) << 2) + (k & 3);
+}
+
+__global__ __launch_bounds__(kThreads) void adam_w_kernel(const AdamWArgs p) {
+  const size_t per = (size_t)p.K * p.N;
+  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= per * p.E) return;
+  const int e = (int)(i / per);
+  const size_t r = i - (size_t)e * per;
+  const int k = (int)(r / p.N), n = (int)(r - (size_t)k * p.N);
+  float w = p.W[i];
+  if (p.apply) {
+    float g = 0.0f;
+    for (int s = 0; s < p.n_parts; ++s) g += p.parts[(size_t)s * p.part_stride + i];
+    g += p.decay * w;                      // d/dw of decay * l2_loss(w), models/pens/fc.py:167-168
+    float m = p.m[i], v = p.v[i];
+    m += (g - m) * (1.0f - p.b1);
+    v += (g * g - v) * (1.0f - p.b2);
+    w -= p.lr_t * m / (sqrtf(v) + p.eps);
+    p.m[i] = m; p.v[i] = v; p.W[i] = w;
+  }
+  p.fwd[(size_t)e * p.f_stride + pack_index(k, n, p.f_kg)] = w;
+  if (p.bwd) p.bwd[(size_t)e * p.b_stride + pack_index(n, k, p.b_kg)] = w;
+}
+
+struct AdamBArgs {
+  float *B, *m, *v;
+  const float *g; int g_ld;
+  float *blob; int blob_ld;
+  int E, N;
+  float lr_t, b1, b2, eps;
+  int apply;
+};
+
+__global__ __launch_bounds__(kThreads) void adam_b_kernel(const AdamBArgs p) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= p.E * p.N) return;
+  const int e = i / p.N, n = i - e * p.N;
+  float w = p.B[i];
+  if (p.apply) {
+    const float g = p.g[(size_t)e * p.g_ld + n];
+    float m = p.m[i], v = p.v[i];
+    m += (g - m) * (1.0f - p.b1);
+    v += (g * g - v) * (1.0f - p.b2);
+    w -= p.lr_t * m / (sqrtf(v) + p.eps);
+    p.m[i] = m; p.v[i] = v; p.B[i] = w;
+  }
+  p.blob[(size_t)e * p.blob_ld + n] = w;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+struct cmbpo_trainer {
+  cmbpo_mlp *m;
+  int E, I, IP, H, O, OPk, D, prob, max_batch;
+  float lr, b1, b2, eps;
+  float decay[3];
+  long step;
+  int ks[3];                     // grid K split of the three weight-gradient GEMMs (fixed at max_batch)
+  float *pool;                   // one allocation
+  float *W[3], *Bv[3], *mW[3], *vW[3], *mB[3], *vB[3];
+  float *wpb1, *wpb2;
+  float *x, *h1, *g1, *h2, *g2, *o, *d3, *d2, *d1;
+  float *parts[3], *dB[3];
+  double *sums;
+  size_t wsize[3], bsize[3];
+};
+
+namespace {
+
+int wgrad_rows_per_wg(int batch, int ks) {
+  int rows = cmbpo_ceil_div(batch, ks);
+  return (rows + 7) / 8 * 8;   // 4 waves x an even row count
+}
+
+int launch_wgrad(cmbpo_trainer *t, int layer, int batch, hipStream_t s) {
+  WgradArgs a{};
+  const int H = t->H;
+  int n_cols;
+  if (layer == 0) {         // dW0[k][n] = sum_b x[b][k] d1[b][n]: computed as (d1^T x), written transposed
+    a.A = t->d1; a.lda = H; a.Bm = t->x; a.ldb = t->IP; n_cols = t->IP;
+    a.ldc = H; a.transposed = 1; a.n_out = t->I;
+  } else if (layer == 1) {  // dW1 = h1^T d2
+    a.A = t->h1; a.lda = H; a.Bm = t->d2; a.ldb = H; n_cols = H;
+    a.ldc = H; a.transposed = 0; a.n_out = H;
+  } else {                  // dW2 = h2^T d3
+    a.A = t->h2; a.lda = H; a.Bm = t->d3; a.ldb = t->OPk; n_cols = t->OPk;
+    a.ldc = t->O; a.transposed = 0; a.n_out = t->O;
+  }
+  a.out = t->parts[layer];
+  a.out_member = t->wsize[layer] / t->E;
+  a.out_part = t->wsize[layer];
+  a.B = batch;
+  a.rows_per_wg = wgrad_rows_per_wg(batch, t->ks[layer]);
+  a.n_tiles = cmbpo_ceil_div(n_cols, 64);
+  const size_t lds = 2 * 128 * 64 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad_kernel, dim3((H / 128) * a.n_tiles, t->ks[layer], t->E), dim3(kThreads), lds, s, a);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+template <int HID>
+int launch_bwd(const BwdArgs &a, int tiles, int E, size_t lds, hipStream_t s) {
+  static size_t attr_bytes = 0;
+  if (lds > attr_bytes) {
+    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_chain_kernel<HID>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_bytes = lds;
+  }
+  hipLaunchKernelGGL(bwd_chain_kernel<HID>, dim3(tiles, E), dim3(kThreads), lds, s, a);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+// masters -> packs (apply == 0) or one Adam step (apply == 1)
+int launch_update(cmbpo_trainer *t, int apply, float lr_t, hipStream_t s) {
+  cmbpo_mlp *m = t->m;
+  const int E = t->E, H = t->H;
+  const int Ks[3] = {t->I, H, H}, Ns[3] = {H, H, t->O};
+  float *fwd[3] = {m->d_blob + m->off_wp0, m->d_blob + m->off_wp1, m->d_blob + m->off_wp2};
+  const int f_kg[3] = {t->IP / 8, H / 8, H / 8};
+  const size_t f_stride[3] = {(size_t)(H / 32) * (t->IP / 8) * 256, (size_t)(H / 32) * (H / 8) * 256,
+                              (size_t)m->o_tiles * (H / 8) * 256};
+  float *bwd[3] = {nullptr, t->wpb1, t->wpb2};
+  const int b_kg[3] = {0, H / 8, t->OPk / 8};
+  const size_t b_stride[3] = {0, (size_t)(H / 32) * (H / 8) * 256, (size_t)(H / 32) * (t->OPk / 8) * 256};
+  float *blob_b[3] = {m->d_blob + m->off_b0, m->d_blob + m->off_b1, m->d_blob + m->off_b2};
+  const int blob_ld[3] = {H, H, m->o_tiles * 32};
+  for (int l = 0; l < 3; ++l) {
+    AdamWArgs a{};
+    a.W = t->W[l]; a.m = t->mW[l]; a.v = t->vW[l];
+    a.parts = t->parts[l]; a.n_parts = t->ks[l]; a.part_stride = t->wsize[l];
+    a.decay = t->decay[l];
+    a.E = E; a.K = Ks[l]; a.N = Ns[l];
+    a.fwd = fwd[l]; a.f_kg = f_kg[l]; a.f_stride = f_stride[l];
+    a.bwd = bwd[l]; a.b_kg = b_kg[l]; a.b_stride = b_stride[l];
+    a.lr_t = lr_t; a.b1 = t->b1; a.b2 = t->b2; a.eps = t->eps; a.apply = apply;
+    const size_t n = t->wsize[l];
+    hipLaunchKernelGGL(adam_w_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, a);
+    AdamBArgs b{};
+    b.B = t->Bv[l]; b.m = t->mB[l]; b.v = t->vB[l];
+    b.g = t->dB[l]; b.g_ld = Ns[l];
+    b.blob = blob_b[l]; b.blob_ld = blob_ld[l];
+    b.E = E; b.N = Ns[l];
+    b.lr_t = lr_t; b.b1 = t->b1; b.b2 = t->b2; b.eps = t->eps; b.apply = apply;
+    hipLaunchKernelGGL(adam_b_kernel, dim3(cmbpo_ceil_div(E * Ns[l], kThreads)), dim3(kThreads), 0, s, b);
+  }
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+int run_forward(cmbpo_trainer *t, const float *d_inputs, const int32_t *d_idx, int idx_stride, int rows, bool exports,
+                hipStream_t s) {
+  MlpKernelArgs a{};
+  a.obs = d_inputs; a.obs_dim = t->I; a.act = nullptr; a.act_dim = 0;
+  a.row_idx = d_idx; a.row_idx_stride = idx_stride;
+  a.n_rows_dev = nullptr; a.n_rows = rows; a.ld_rows = rows;
+  a.out0 = t->o;
+  if (exports) { a.tr_x = t->x; a.tr_h1 = t->h1; a.tr_g1 = t->g1; a.tr_h2 = t->h2; a.tr_g2 = t->g2; }
+  return cmbpo_internal_launch_mlp(t->m, a, s, CMBPO_HEAD_TRAIN);
+}
+
+void fill_loss_args(cmbpo_trainer *t, LossArgs &l, const float *d_targets, const int32_t *d_idx, int idx_stride, int rows) {
+  cmbpo_mlp *m = t->m;
+  l.o = t->o; l.targets = d_targets; l.idx = d_idx; l.idx_stride = idx_stride;
+  l.out_mu = m->has_out_scaler ? m->d_blob + m->off_out_mu : nullptr;
+  l.out_sig = m->has_out_scaler ? m->d_blob + m->off_out_var : nullptr;
+  l.E = t->E; l.B = rows; l.O = t->O; l.D = t->D; l.OPk = t->OPk; l.prob = t->prob;
+  l.sums = t->sums; l.d3 = t->d3;
+}
+
+}  // namespace
+
+extern "C" int cmbpo_trainer_create(cmbpo_trainer_t **out, cmbpo_mlp_t *m, int max_batch, float lr,
+                                    const double *decays) {
+  CMBPO_REQUIRE(out && m && decays, "cmbpo_trainer_create: NULL argument");
+  CMBPO_REQUIRE(m->head == CMBPO_HEAD_PROB || m->head == CMBPO_HEAD_DETMEAN,
+                "cmbpo_trainer_create: only ensemble handles (HEAD_PROB / HEAD_DETMEAN) train");
+  CMBPO_REQUIRE(m->act == CMBPO_ACT_SWISH, "cmbpo_trainer_create: only swish ensembles train");
+  CMBPO_REQUIRE(max_batch >= 1 && max_batch <= (1 << 20), "cmbpo_trainer_create: max_batch %d out of range", max_batch);
+  cmbpo_trainer *t = new (std::nothrow) cmbpo_trainer();
+  if (!t) { cmbpo_set_error("cmbpo_trainer_create: out of host memory"); return CMBPO_ENOMEM; }
+  t->m = m;
+  t->E = m->ensemble; t->I = m->in_dim; t->IP = m->in_pad; t->H = m->hidden; t->O = m->o_width;
+  t->OPk = (m->o_width + 7) / 8 * 8; t->D = m->out_dim; t->prob = m->head == CMBPO_HEAD_PROB;
+  t->max_batch = max_batch;
+  t->lr = lr; t->b1 = 0.9f; t->b2 = 0.999f; t->eps = 1e-8f;
+  for (int l = 0; l < 3; ++l) t->decay[l] = (float)decays[l];
+  t->step = 0;
+  const int E = t->E, H = t->H;
+  t->wsize[0] = (size_t)E * t->I * H; t->wsize[1] = (size_t)E * H * H; t->wsize[2] = (size_t)E * H * t->O;
+  t->bsize[0] = (size_t)E * H; t->bsize[1] = (size_t)E * H; t->bsize[2] = (size_t)E * t->O;
+  // grid K split: enough workgroups to cover the chip about twice, at least 8 batch rows per workgroup
+  const int n_tiles[3] = {cmbpo_ceil_div(t->IP, 64), H / 64, cmbpo_ceil_div(t->OPk, 64)};
+  for (int l = 0; l < 3; ++l) {
+    const int wgs = (H / 128) * n_tiles[l] * E;
+    int ks = cmbpo_ceil_div(512, wgs);
+    const int max_ks = max_batch / 32 < 1 ? 1 : max_batch / 32;
+    if (ks > max_ks) ks = max_ks;
+    if (ks > 16) ks = 16;
+    t->ks[l] = ks < 1 ? 1 : ks;
+  }
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; };
+  size_t oW[3], oB[3], omW[3], ovW[3], omB[3], ovB[3], oP[3], odB[3];
+  for (int l = 0; l < 3; ++l) {
+    oW[l] = take(t->wsize[l]); omW[l] = take(t->wsize[l]); ovW[l] = take(t->wsize[l]);
+    oB[l] = take(t->bsize[l]); omB[l] = take(t->bsize[l]); ovB[l] = take(t->bsize[l]);
+    oP[l] = take(t->wsize[l] * t->ks[l]); odB[l] = take(t->bsize[l]);
+  }
+  const size_t owpb1 = take((size_t)E * (H / 32) * (H / 8) * 256);
+  const size_t owpb2 = take((size_t)E * (H / 32) * (t->OPk / 8) * 256);
+  const size_t rows = (size_t)E * max_batch;
+  const size_t ox = take(rows * t->IP), oh1 = take(rows * H), og1 = take(rows * H), oh2 = take(rows * H),
+               og2 = take(rows * H), oo = take(rows * t->O), od3 = take(rows * t->OPk), od2 = take(rows * H),
+               od1 = take(rows * H);
+  const size_t osums = take(2 * 3 * (size_t)E);   // doubles
+  hipError_t err = hipMalloc(reinterpret_cast<void **>(&t->pool), off * sizeof(float));
+  if (err != hipSuccess) {
+    cmbpo_set_error("cmbpo_trainer_create: hipMalloc(%zu) failed: %s", off * sizeof(float), hipGetErrorString(err));
+    delete t;
+    return CMBPO_ENOMEM;
+  }
+  err = hipMemset(t->pool, 0, off * sizeof(float));   // Adam moments, pack padding
+  if (err != hipSuccess) {
+    cmbpo_set_error("cmbpo_trainer_create: hipMemset failed: %s", hipGetErrorString(err));
+    (void)hipFree(t->pool);
+    delete t;
+    return CMBPO_EHIP;
+  }
+  float *P = t->pool;
+  for (int l = 0; l < 3; ++l) {
+    t->W[l] = P + oW[l]; t->mW[l] = P + omW[l]; t->vW[l] = P + ovW[l];
+    t->Bv[l] = P + oB[l]; t->mB[l] = P + omB[l]; t->vB[l] = P + ovB[l];
+    t->parts[l] = P + oP[l]; t->dB[l] = P + odB[l];
+  }
+  t->wpb1 = P + owpb1; t->wpb2 = P + owpb2;
+  t->x = P + ox; t->h1 = P + oh1; t->g1 = P + og1; t->h2 = P + oh2; t->g2 = P + og2;
+  t->o = P + oo; t->d3 = P + od3; t->d2 = P + od2; t->d1 = P + od1;
+  t->sums = reinterpret_cast<double *>(P + osums);
+  *out = t;
+  return CMBPO_OK;
+}
+
+extern "C" void cmbpo_trainer_destroy(cmbpo_trainer_t *t) {
+  if (!t) return;
+  if (t->pool) (void)hipFree(t->pool);
+  delete t;
+}
+
+extern "C" int cmbpo_trainer_set_weights(cmbpo_trainer_t *t, const float *h_w0, const float *h_b0, const float *h_w1,
+                                         const float *h_b1, const float *h_w2, const float *h_b2, void *stream) {
+  CMBPO_REQUIRE(t && h_w0 && h_b0 && h_w1 && h_b1 && h_w2 && h_b2, "cmbpo_trainer_set_weights: NULL argument");
+  hipStream_t s = (hipStream_t)stream;
+  const float *hw[3] = {h_w0, h_w1, h_w2}, *hb[3] = {h_b0, h_b1, h_b2};
+  for (int l = 0; l < 3; ++l) {
+    CMBPO_HIP_CHECK(hipMemcpyAsync(t->W[l], hw[l], t->wsize[l] * sizeof(float), hipMemcpyHostToDevice, s));
+    CMBPO_HIP_CHECK(hipMemcpyAsync(t->Bv[l], hb[l], t->bsize[l] * sizeof(float), hipMemcpyHostToDevice, s));
+  }
+  // the packed images (and their zero padding) are rebuilt from the masters
+  cmbpo_mlp *m = t->m;
+  CMBPO_HIP_CHECK(hipMemsetAsync(m->d_blob + m->off_wp0, 0, (m->off_in_mu - m->off_wp0) * sizeof(float), s));
+  const int rc = launch_update(t, 0, 0.0f, s);
+  if (rc != CMBPO_OK) return rc;
+  CMBPO_HIP_CHECK(hipStreamSynchronize(s));   // the host arrays may be pageable temporaries
+  m->loaded = true;
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_trainer_get_weights(cmbpo_trainer_t *t, float *h_w0, float *h_b0, float *h_w1, float *h_b1,
+                                         float *h_w2, float *h_b2, void *stream) {
+  CMBPO_REQUIRE(t && h_w0 && h_b0 && h_w1 && h_b1 && h_w2 && h_b2, "cmbpo_trainer_get_weights: NULL argument");
+  hipStream_t s = (hipStream_t)stream;
+  float *hw[3] = {h_w0, h_w1, h_w2}, *hb[3] = {h_b0, h_b1, h_b2};
+  for (int l = 0; l < 3; ++l) {
+    CMBPO_HIP_CHECK(hipMemcpyAsync(hw[l], t->W[l], t->wsize[l] * sizeof(float), hipMemcpyDeviceToHost, s));
+    CMBPO_HIP_CHECK(hipMemcpyAsync(hb[l], t->Bv[l], t->bsize[l] * sizeof(float), hipMemcpyDeviceToHost, s));
+  }
+  CMBPO_HIP_CHECK(hipStreamSynchronize(s));
+  return CMBPO_OK;
+}
+
+// Adam state in and out (which: 0 first moment, 1 second moment): optimizer checkpoint / resume
+extern "C" int cmbpo_trainer_get_moments(cmbpo_trainer_t *t, int which, float *h_w0, float *h_b0, float *h_w1,
+                                         float *h_b1, float *h_w2, float *h_b2, void *stream) {
+  CMBPO_REQUIRE(t && h_w0 && h_b0 && h_w1 && h_b1 && h_w2 && h_b2, "cmbpo_trainer_get_moments: NULL argument");
+  CMBPO_REQUIRE(which == 0 || which == 1, "cmbpo_trainer_get_moments: which must be 0 (m) or 1 (v)");
+  hipStream_t s = (hipStream_t)stream;
+  float *hw[3] = {h_w0, h_w1, h_w2}, *hb[3] = {h_b0, h_b1, h_b2};
+  for (int l = 0; l < 3; ++l) {
+    CMBPO_HIP_CHECK(hipMemcpyAsync(hw[l], which ? t->vW[l] : t->mW[l], t->wsize[l] * sizeof(float), hipMemcpyDeviceToHost, s));
+    CMBPO_HIP_CHECK(hipMemcpyAsync(hb[l], which ? t->vB[l] : t->mB[l], t->bsize[l] * sizeof(float), hipMemcpyDeviceToHost, s));
+  }
+  CMBPO_HIP_CHECK(hipStreamSynchronize(s));
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_trainer_set_moments(cmbpo_trainer_t *t, int which, const float *h_w0, const float *h_b0,
+                                         const float *h_w1, const float *h_b1, const float *h_w2, const float *h_b2,
+                                         long steps_done, void *stream) {
+  CMBPO_REQUIRE(t && h_w0 && h_b0 && h_w1 && h_b1 && h_w2 && h_b2, "cmbpo_trainer_set_moments: NULL argument");
+  CMBPO_REQUIRE(which == 0 || which == 1, "cmbpo_trainer_set_moments: which must be 0 (m) or 1 (v)");
+  CMBPO_REQUIRE(steps_done >= 0, "cmbpo_trainer_set_moments: negative step count");
+  hipStream_t s = (hipStream_t)stream;
+  const float *hw[3] = {h_w0, h_w1, h_w2}, *hb[3] = {h_b0, h_b1, h_b2};
+  for (int l = 0; l < 3; ++l) {
+    CMBPO_HIP_CHECK(hipMemcpyAsync(which ? t->vW[l] : t->mW[l], hw[l], t->wsize[l] * sizeof(float), hipMemcpyHostToDevice, s));
+    CMBPO_HIP_CHECK(hipMemcpyAsync(which ? t->vB[l] : t->mB[l], hb[l], t->bsize[l] * sizeof(float), hipMemcpyHostToDevice, s));
+  }
+  CMBPO_HIP_CHECK(hipStreamSynchronize(s));
+  t->step = steps_done;
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_trainer_reset_optimizer(cmbpo_trainer_t *t, void *stream) {
+  CMBPO_REQUIRE(t != nullptr, "cmbpo_trainer_reset_optimizer: handle is NULL");
+  hipStream_t s = (hipStream_t)stream;
+  for (int l = 0; l < 3; ++l) {
+    CMBPO_HIP_CHECK(hipMemsetAsync(t->mW[l], 0, t->wsize[l] * sizeof(float), s));
+    CMBPO_HIP_CHECK(hipMemsetAsync(t->vW[l], 0, t->wsize[l] * sizeof(float), s));
+    CMBPO_HIP_CHECK(hipMemsetAsync(t->mB[l], 0, t->bsize[l] * sizeof(float), s));
+    CMBPO_HIP_CHECK(hipMemsetAsync(t->vB[l], 0, t->bsize[l] * sizeof(float), s));
+  }
+  t->step = 0;
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_mlp_set_scalers(cmbpo_mlp_t *m, const float *h_in_mu, const float *h_in_var,
+                                     const float *h_out_mu, const float *h_out_var, void *stream) {
+  CMBPO_REQUIRE(m != nullptr, "cmbpo_mlp_set_scalers: handle is NULL");
+  CMBPO_REQUIRE((h_in_mu == nullptr) == (h_in_var == nullptr), "cmbpo_mlp_set_scalers: in scaler needs both mu and var");
+  CMBPO_REQUIRE((h_out_mu == nullptr) == (h_out_var == nullptr), "cmbpo_mlp_set_scalers: out scaler needs both mu and var");
+  hipStream_t s = (hipStream_t)stream;
+  const int I = m->in_dim, D = m->out_dim;
+  std::vector<float> tmp(2 * (size_t)I + 3 * (size_t)D);
+  // sigma = max(sqrt(var), 1e-2) in float32, as cmbpo_mlp_load (models/pens/utils.py:156,167,187)
+  if (h_in_mu) {
+    for (int k = 0; k < I; ++k) { tmp[k] = h_in_mu[k]; tmp[I + k] = fmaxf(sqrtf(h_in_var[k]), 1e-2f); }
+    CMBPO_HIP_CHECK(hipMemcpyAsync(m->d_blob + m->off_in_mu, tmp.data(), I * sizeof(float), hipMemcpyHostToDevice, s));
+    CMBPO_HIP_CHECK(hipMemcpyAsync(m->d_blob + m->off_in_var, tmp.data() + I, I * sizeof(float), hipMemcpyHostToDevice, s));
+  }
+  if (h_out_mu) {
+    float *o = tmp.data() + 2 * (size_t)I;
+    for (int k = 0; k < D; ++k) {
+      const float sig = fmaxf(sqrtf(h_out_var[k]), 1e-2f);
+      o[k] = h_out_mu[k]; o[D + k] = sig; o[2 * D + k] = 2.0f * logf(sig);
+    }
+    CMBPO_HIP_CHECK(hipMemcpyAsync(m->d_blob + m->off_out_mu, o, D * sizeof(float), hipMemcpyHostToDevice, s));
+    CMBPO_HIP_CHECK(hipMemcpyAsync(m->d_blob + m->off_out_var, o + D, D * sizeof(float), hipMemcpyHostToDevice, s));
+    CMBPO_HIP_CHECK(hipMemcpyAsync(m->d_blob + m->off_out_lsig2, o + 2 * D, D * sizeof(float), hipMemcpyHostToDevice, s));
+  }
+  CMBPO_HIP_CHECK(hipStreamSynchronize(s));   // tmp goes out of scope
+  m->has_in_scaler = m->has_in_scaler || h_in_mu != nullptr;
+  m->has_out_scaler = m->has_out_scaler || h_out_mu != nullptr;
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_trainer_step(cmbpo_trainer_t *t, const float *d_inputs, int in_dim, const float *d_targets,
+                                  int target_dim, const int32_t *d_idx, int idx_stride, int batch, void *stream) {
+  CMBPO_REQUIRE(t && d_inputs && d_targets, "cmbpo_trainer_step: NULL argument");
+  if (!t->m->loaded) { cmbpo_set_error("cmbpo_trainer_step: weights not loaded"); return CMBPO_ESTATE; }
+  CMBPO_REQUIRE(in_dim == t->I, "cmbpo_trainer_step: in_dim %d != %d", in_dim, t->I);
+  CMBPO_REQUIRE(target_dim == t->D, "cmbpo_trainer_step: target_dim %d != %d", target_dim, t->D);
+  CMBPO_REQUIRE(batch >= 1 && batch <= t->max_batch, "cmbpo_trainer_step: batch %d not in [1, %d]", batch, t->max_batch);
+  CMBPO_REQUIRE(d_idx == nullptr || idx_stride >= 0, "cmbpo_trainer_step: negative idx_stride");
+  hipStream_t s = (hipStream_t)stream;
+  const int E = t->E, H = t->H;
+
+  int rc = run_forward(t, d_inputs, d_idx, idx_stride, batch, true, s);
+  if (rc != CMBPO_OK) return rc;
+
+  LossArgs l{};
+  fill_loss_args(t, l, d_targets, d_idx, idx_stride, batch);
+  CMBPO_HIP_CHECK(hipMemsetAsync(t->sums, 0, 3 * (size_t)E * sizeof(double), s));
+  if (t->prob) {   // the MSE gradient needs no batch statistic
+    const int gx = min(cmbpo_ceil_div(batch * t->D, kThreads), 64);
+    hipLaunchKernelGGL(loss_sums_kernel, dim3(gx, E), dim3(kThreads), 0, s, l);
+  }
+  const size_t total = (size_t)E * batch * t->OPk;
+  hipLaunchKernelGGL(loss_delta_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, l);
+  CMBPO_HIP_CHECK(hipGetLastError());
+
+  BwdArgs b{};
+  b.wpb2 = reinterpret_cast<const f32x4 *>(t->wpb2); b.wpb1 = reinterpret_cast<const f32x4 *>(t->wpb1);
+  b.wpb2_stride = (size_t)(H / 32) * (t->OPk / 8) * 64; b.wpb1_stride = (size_t)(H / 32) * (H / 8) * 64;
+  b.d3 = t->d3; b.g2 = t->g2; b.g1 = t->g1; b.d2 = t->d2; b.d1 = t->d1;
+  b.B = batch; b.OPk = t->OPk;
+  const size_t lds = ((size_t)H / 4 * 32 + (size_t)t->OPk / 4 * 32) * sizeof(f32x4);
+  const int tiles = cmbpo_ceil_div(batch, 32);
+  rc = (H == 512) ? launch_bwd<512>(b, tiles, E, lds, s) : launch_bwd<128>(b, tiles, E, lds, s);
+  if (rc != CMBPO_OK) return rc;
+
+  for (int layer = 0; layer < 3; ++layer) {
+    rc = launch_wgrad(t, layer, batch, s);
+    if (rc != CMBPO_OK) return rc;
+  }
+  hipLaunchKernelGGL(colsum_kernel, dim3(H / 64, E), dim3(kThreads), 0, s, t->d1, H, H, batch, t->dB[0], H);
+  hipLaunchKernelGGL(colsum_kernel, dim3(H / 64, E), dim3(kThreads), 0, s, t->d2, H, H, batch, t->dB[1], H);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cmbpo_ceil_div(t->O, 64), E), dim3(kThreads), 0, s, t->d3, t->OPk, t->O, batch,
+                     t->dB[2], t->O);
+  CMBPO_HIP_CHECK(hipGetLastError());
+
+  t->step += 1;
+  const double lr_t = (double)t->lr * sqrt(1.0 - pow((double)t->b2, (double)t->step)) / (1.0 - pow((double)t->b1, (double)t->step));
+  return launch_update(t, 1, (float)lr_t, s);
+}
+
+extern "C" int cmbpo_trainer_losses(cmbpo_trainer_t *t, const float *d_inputs, int in_dim, const float *d_targets,
+                                    int target_dim, const int32_t *d_idx, int idx_stride, int n_rows, float *d_losses,
+                                    void *stream) {
+  CMBPO_REQUIRE(t && d_inputs && d_targets && d_losses, "cmbpo_trainer_losses: NULL argument");
+  if (!t->m->loaded) { cmbpo_set_error("cmbpo_trainer_losses: weights not loaded"); return CMBPO_ESTATE; }
+  CMBPO_REQUIRE(in_dim == t->I && target_dim == t->D, "cmbpo_trainer_losses: dims (%d, %d) != (%d, %d)", in_dim, target_dim, t->I, t->D);
+  CMBPO_REQUIRE(n_rows >= 1, "cmbpo_trainer_losses: n_rows %d", n_rows);
+  CMBPO_REQUIRE(d_idx != nullptr || n_rows <= t->max_batch, "cmbpo_trainer_losses: %d direct rows exceed max_batch %d (pass an index list)",
+                n_rows, t->max_batch);
+  hipStream_t s = (hipStream_t)stream;
+  const int E = t->E;
+  CMBPO_HIP_CHECK(hipMemsetAsync(t->sums, 0, 3 * (size_t)E * sizeof(double), s));
+  for (int r0 = 0; r0 < n_rows; r0 += t->max_batch) {
+    const int rows = min(t->max_batch, n_rows - r0);
+    const int32_t *idx = d_idx ? d_idx + r0 : nullptr;
+    int rc = run_forward(t, d_inputs, idx, idx_stride, rows, false, s);
+    if (rc != CMBPO_OK) return rc;
+    LossArgs l{};
+    fill_loss_args(t, l, d_targets, idx, idx_stride, rows);
+    l.prob = 0;   // only the squared error of the mean head is needed
+    const int gx = min(cmbpo_ceil_div(rows * t->D, kThreads), 64);
+    hipLaunchKernelGGL(loss_sums_kernel, dim3(gx, E), dim3(kThreads), 0, s, l);
+  }
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, t->sums, E, 1.0 / ((double)n_rows * t->D), d_losses);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+extern "C" long cmbpo_trainer_steps_done(const cmbpo_trainer_t *t) { return t ? t->step : -1; }

@@ -337,6 +337,55 @@ int cmbpo_vec_lincomb(int P, float a, const float *d_x, float b, const float *d_
  * host arrays of device pointers. */
 int cmbpo_vec_dots(int P, int n, const float *const *h_x, const float *const *h_y, double *d_out, void *stream);
 
+/* ---- ensemble training (csrc/ens_train.hip) -------------------------
+ * The TensorFlow train_op of the reference ensembles (models/pens/pe.py:252-274,312-318:
+ * train_loss = sum_e loss_e + sum_l decay_l * l2_loss(W_l), tf.train.AdamOptimizer(lr)) for the
+ * two losses the shipped configs use: 'MSPE' on HEAD_PROB handles (pe.py:921-973, dynamics)
+ * and 'MSE' on HEAD_DETMEAN handles (pe.py:840-919 with inc_var_loss=False, critics).  The
+ * trainer owns the row-major master weights and Adam moments and keeps the handle's packed
+ * weights (what cmbpo_ens_forward / cmbpo_ens_predict_mean read) in step with them. */
+typedef struct cmbpo_trainer cmbpo_trainer_t;
+
+/* decays[3] = weight_decay of the three FC layers (pe_factory.py:50-55: decay/4, decay/2,
+ * decay); max_batch bounds the rows of one step (activations are kept for the backward pass). */
+int cmbpo_trainer_create(cmbpo_trainer_t **out, cmbpo_mlp_t *m, int max_batch, float lr,
+                         const double *decays);
+void cmbpo_trainer_destroy(cmbpo_trainer_t *t);
+/* Host weights in the reference variable layout (W[E][in][out], b[E][out]) -> masters and the
+ * handle's packed images; the Adam state is untouched (the reference keeps it across train()
+ * calls, pe.py:318).  get_weights copies the masters back (checkpointing, models/pens/pe.py:736-764). */
+int cmbpo_trainer_set_weights(cmbpo_trainer_t *t, const float *h_w0, const float *h_b0,
+                              const float *h_w1, const float *h_b1, const float *h_w2,
+                              const float *h_b2, void *stream);
+int cmbpo_trainer_get_weights(cmbpo_trainer_t *t, float *h_w0, float *h_b0, float *h_w1,
+                              float *h_b1, float *h_w2, float *h_b2, void *stream);
+int cmbpo_trainer_reset_optimizer(cmbpo_trainer_t *t, void *stream);
+/* Adam moments (which: 0 = m, 1 = v) in the layout of the weights, and the step count t of
+ * lr_t = lr sqrt(1 - b2^t) / (1 - b1^t): optimizer checkpoint / resume (the reference saves
+ * optimizer.variables() with the model, pe.py:318,736-764). */
+int cmbpo_trainer_get_moments(cmbpo_trainer_t *t, int which, float *h_w0, float *h_b0, float *h_w1,
+                              float *h_b1, float *h_w2, float *h_b2, void *stream);
+int cmbpo_trainer_set_moments(cmbpo_trainer_t *t, int which, const float *h_w0, const float *h_b0,
+                              const float *h_w1, const float *h_b1, const float *h_w2,
+                              const float *h_b2, long steps_done, void *stream);
+/* TensorStandardScaler.fit result (models/pens/utils.py:119-138) -> the handle, without touching
+ * the weights; NULL pairs are left as they are. */
+int cmbpo_mlp_set_scalers(cmbpo_mlp_t *m, const float *h_in_mu, const float *h_in_var,
+                          const float *h_out_mu, const float *h_out_var, void *stream);
+/* One sess.run(train_op) (pe.py:541-563): member e trains on rows d_idx[e * idx_stride + b],
+ * b < batch, of d_inputs[N][in_dim] / d_targets[N][target_dim] (inputs[batch_idxs], pe.py:543-547);
+ * d_idx == NULL takes rows 0..batch-1 for every member. */
+int cmbpo_trainer_step(cmbpo_trainer_t *t, const float *d_inputs, int in_dim,
+                       const float *d_targets, int target_dim, const int32_t *d_idx,
+                       int idx_stride, int batch, void *stream);
+/* sess.run(self.loss) (pe.py:264,582-603,629-635): d_losses[e] = 0.5 * mean over rows and
+ * target dims of (mean head - scaled target)^2; idx_stride 0 evaluates every member on the same
+ * rows (the tiled holdout set). */
+int cmbpo_trainer_losses(cmbpo_trainer_t *t, const float *d_inputs, int in_dim,
+                         const float *d_targets, int target_dim, const int32_t *d_idx,
+                         int idx_stride, int n_rows, float *d_losses, void *stream);
+long cmbpo_trainer_steps_done(const cmbpo_trainer_t *t);
+
 #ifdef __cplusplus
 }
 #endif

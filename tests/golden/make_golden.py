@@ -348,6 +348,7 @@ def main():
     gen_sampler_traces(HERE)
     gen_update_pi(HERE)
     gen_cpobuffer(HERE)
+    gen_pe_train(HERE)
     print("golden vectors written to", HERE)
 
 
@@ -480,8 +481,127 @@ def gen_cpobuffer(out):
     print("cpobuffer: samples", n, "archive", buf.arch_size)
 
 
+# ------------------------------------------------------------------------------------------------
+# G9: the reference's PE.train control flow (and TensorStandardScaler.fit) driven by a fake session
+# ------------------------------------------------------------------------------------------------
+def gen_pe_train(out):
+    """PE.train (models/pens/pe.py:457-646), _save_best / _end_train (:367-400) and TensorStandardScaler.fit
+    (models/pens/utils.py:119-138,220-231) are the reference's code; the session is a stand-in that records
+    which rows every train_op is fed (column 0 of the inputs carries the row id) and answers `self.loss` with a
+    scripted sequence of holdout losses, so the NumPy half of training is pinned without TensorFlow."""
+    import contextlib
+    from models.pens.pe import PE
+    from models.pens.utils import TensorStandardScaler
+
+    class Var:
+        def __init__(self, v):
+            self.v = np.asarray(v, np.float32)
+
+        def load(self, v):
+            self.v = np.asarray(v, np.float32)      # the TF variables are float32
+
+        def eval(self):
+            return self.v
+
+    def make_scaler(dim):
+        sc = object.__new__(TensorStandardScaler)
+        sc.fitted = False
+        sc.count, sc.mu, sc.var = Var(0.0), Var(np.zeros([1, dim])), Var(np.ones([1, dim]))
+        sc.cached_count, sc.cached_mu, sc.cached_var = 0, np.zeros([1, dim]), np.ones([1, dim])
+        return sc
+
+    class Sess:
+        def __init__(self, script):
+            self.script, self.k = script, 0
+            self.steps, self.holdout_rows = [], None
+
+        @contextlib.contextmanager
+        def as_default(self):
+            yield self
+
+        def run(self, op, feed_dict=None):
+            x = feed_dict["in"]
+            if op == "train_op":
+                self.steps.append(x[..., 0].astype(np.int32))
+                return None
+            if op == "loss":
+                rows = x[0, :, 0].astype(np.int32)
+                if self.holdout_rows is not None and rows.shape == self.holdout_rows.shape and \
+                        np.array_equal(rows, self.holdout_rows):
+                    losses = self.script(self.k)
+                    self.k += 1
+                    return losses
+                return np.zeros(x.shape[0])            # the progress-bar evaluation on training rows
+            return [np.zeros(1), np.zeros(1)]          # [tensor_loss, debug_mean]: display only
+
+    cases = {}
+    scen = [  # name, n, E, elites, batch, kwargs, script
+        ("early_stop", 230, 5, 3, 32, dict(max_epochs=40, holdout_ratio=0.2, max_epochs_since_update=3, min_epoch_before_break=4),
+         lambda k: np.array([1.0, 2.0, 0.5, 3.0, 1.5]) * (0.8 ** min(k, 6)) + 0.01 * np.array([3, 1, 4, 1, 5]) * (k % 3)),
+        ("max_epochs", 100, 3, 2, 64, dict(max_epochs=5, holdout_ratio=0.1, min_epoch_before_break=5),
+         lambda k: np.array([0.3, 0.1, 0.2]) / (1.0 + k)),
+        ("grad_updates", 157, 4, 2, 16, dict(max_epochs=50, holdout_ratio=0.25, max_grad_updates=30),
+         lambda k: np.array([4.0, 3.0, 2.0, 1.0]) * (0.99 ** k)),
+        ("max_logging", 400, 2, 1, 128, dict(max_epochs=2, holdout_ratio=0.5, max_logging=50),
+         lambda k: np.array([1.0, 1.0 - 0.2 * k])),
+    ]
+    for name, n, E, n_el, bs, kw, script in scen:
+        seed = int(len(name) * 17 + n)
+        rs = np.random.RandomState(seed + 1)
+        in_dim, out_dim = 4, 2
+        inputs = rs.standard_normal((n, in_dim)).astype(np.float32)
+        inputs[:, 0] = np.arange(n)
+        targets = rs.standard_normal((n, out_dim)).astype(np.float32)
+        fake = types.SimpleNamespace()
+        fake.num_nets, fake.num_elites, fake.name = E, n_el, "G9"
+        fake.clip_loss, fake.loss_type, fake.weights = False, "MSPE", None
+        fake.use_scaler_in = fake.use_scaler_out = True
+        fake.scaler_in, fake.scaler_out = make_scaler(in_dim), make_scaler(out_dim)
+        fake.sy_train_in, fake.sy_train_targ = "in", "targ"
+        fake.train_op, fake.loss, fake.tensor_loss, fake.debug_mean = "train_op", "loss", "tensor_loss", "debug_mean"
+        sess = Sess(script)
+        fake.sess = sess
+        fake.layers = []
+        for meth in ("_start_train", "_save_best", "_save_state", "_end_train"):
+            setattr(fake, meth, types.MethodType(getattr(PE, meth), fake))
+        # the holdout rows are what the permutation draws first: replay the generator to know them
+        probe = np.random.RandomState(seed)
+        perm = probe.permutation(n)
+        num_holdout = min(int(n * kw.get("holdout_ratio", 0.0)), kw.get("max_logging", 5000))
+        sess.holdout_rows = perm[:num_holdout].astype(np.int32)
+        np.random.seed(seed)
+        metrics = PE.train(fake, inputs, targets, batch_size=bs, **kw)
+        steps = sess.steps
+        widths = np.array([s.shape[1] for s in steps], np.int32)
+        flat = np.concatenate([s.reshape(-1) for s in steps])
+        pre = name + "/"
+        cases[pre + "seed"], cases[pre + "n"], cases[pre + "E"] = seed, n, E
+        cases[pre + "num_elites"], cases[pre + "batch_size"] = n_el, bs
+        for k, v in kw.items():
+            cases[pre + "kw_" + k] = v
+        cases[pre + "inputs"], cases[pre + "targets"] = inputs, targets
+        cases[pre + "step_widths"], cases[pre + "step_rows"] = widths, flat
+        cases[pre + "holdout_rows"] = sess.holdout_rows
+        cases[pre + "script"] = np.stack([script(k) for k in range(sess.k)])
+        cases[pre + "elites"] = np.asarray(fake._model_inds, np.int32)
+        cases[pre + "val_loss"] = float(list(metrics.values())[0])
+        cases[pre + "in_mu"], cases[pre + "in_var"] = fake.scaler_in.cached_mu, fake.scaler_in.cached_var
+        cases[pre + "out_mu"], cases[pre + "out_var"] = fake.scaler_out.cached_mu, fake.scaler_out.cached_var
+        # a second fit on other rows exercises the running-moment branch (count > 0)
+        more = rs.standard_normal((57, in_dim)).astype(np.float32) * 2 + 1
+        with sess.as_default():
+            fake.scaler_in.fit(more)
+        cases[pre + "more"], cases[pre + "in_mu2"], cases[pre + "in_var2"] = more, fake.scaler_in.cached_mu, fake.scaler_in.cached_var
+        cases[pre + "in_count2"] = float(fake.scaler_in.cached_count)
+        print("pe_train", name, "steps", len(steps), "holdout evals", sess.k, "elites", fake._model_inds)
+    np.savez_compressed(os.path.join(out, "g9_pe_train.npz"), **cases)
+
+
 if __name__ == "__main__":
-    if "--cpobuffer-only" in sys.argv:
+    if "--pe-train-only" in sys.argv:
+        install_stubs()
+        gen_pe_train(HERE)
+    elif "--cpobuffer-only" in sys.argv:
         install_stubs()
         gen_cpobuffer(HERE)
     elif "--update-only" in sys.argv:

@@ -1,0 +1,189 @@
+"""GPU parity of ensemble training against oracle/reftrain.py.
+
+The TensorFlow half of the oracle is "parity unpinned" (TF 1.14 cannot run here): the torch-autograd restatement
+of the training graph is the checker, the analytic cross-checks of tests/test_oracle_train.py pin it.
+
+Tolerances (fp32; sums over the batch in a different order than the oracle):
+  * gradients (read back as 10 x the first Adam moment after step 1): |d| <= 2e-3 |ref| + 5e-5 max|ref| per tensor;
+  * per-member losses: rtol 2e-4;
+  * k Adam steps: || w_hip - w_ref || <= 3e-2 || w_ref - w_init || (the first steps are ~ lr * sign(g), so a
+    near-zero gradient component may legitimately differ by a whole step).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, GOLD)
+
+from oracle import reftrain  # noqa: E402
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _make(E, I, H, D, loss, n, seed, use_scalers=True, lr=1e-3, decay=1e-3):
+    from cmbpo_amd.pens import PE
+    rng = np.random.RandomState(seed)
+    pe = PE(I, D, name="T", hidden_dims=(H, H), num_networks=E, num_elites=max(1, E - 2), loss=loss,
+            use_scaler_in=use_scalers, use_scaler_out=use_scalers, device="cuda:0", lr=lr, decay=decay)
+    ws, bs = pe.init_weights(rng)
+    # non-zero biases and a livelier output layer so every gradient path carries signal
+    bs = [(0.1 * rng.standard_normal(b.shape)).astype(np.float32) for b in bs]
+    ws[2] = (ws[2] * 3).astype(np.float32)
+    x = (rng.standard_normal((n, I)) * (1 + rng.rand(I)) + rng.standard_normal(I)).astype(np.float32)
+    wtrue = rng.standard_normal((I, D)) / np.sqrt(I)
+    t = (np.tanh(x @ wtrue) + 0.1 * rng.standard_normal((n, D))).astype(np.float32)
+    sc_in = sc_out = None
+    if use_scalers:
+        sc_in = (x.mean(0, keepdims=True), x.var(0, keepdims=True))
+        sc_out = (t.mean(0, keepdims=True), t.var(0, keepdims=True))
+    pe.set_weights(ws, bs, sc_in, sc_out)
+    ref = reftrain.EnsembleTrainer(ws, bs, loss_type=loss, decays=pe.decays, lr=lr)
+    ref.set_scalers(sc_in, sc_out)
+    return rng, pe, ref, x, t, ws, bs
+
+
+def _close(got, ref, rtol, arel, msg):
+    np.testing.assert_allclose(got, ref, rtol=rtol, atol=arel * float(np.max(np.abs(ref))) + 1e-12, err_msg=msg)
+
+
+CASES = [  # E, I, H, D, loss, batch
+    (3, 11, 128, 4, "MSPE", 100),
+    (7, 37, 512, 30, "MSPE", 256),
+    (3, 29, 128, 1, "MSE", 77),
+    (2, 20, 512, 1, "MSE", 64),
+    (4, 8, 128, 3, "MSPE", 32),
+]
+
+
+@pytest.mark.parametrize("E,I,H,D,loss,batch", CASES)
+def test_first_step_gradients_and_losses(hip_lib, E, I, H, D, loss, batch):
+    _need_gpu()
+    rng, pe, ref, x, t, ws, bs = _make(E, I, H, D, loss, 600, seed=E * 1000 + I)
+    tr = pe._ensure_trainer(batch)
+    idx = rng.randint(0, x.shape[0], size=(E, batch)).astype(np.int32)
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    idx_d = torch.from_numpy(idx).cuda()
+    # `self.loss` before the step
+    hold = rng.permutation(x.shape[0])[:157].astype(np.int32)
+    got_l = tr.losses(xd, td, torch.from_numpy(hold).cuda(), 0, hold.shape[0]).cpu().numpy()
+    ref_l = ref.losses(np.tile(x[hold][None], (E, 1, 1)), np.tile(t[hold][None], (E, 1, 1)))
+    np.testing.assert_allclose(got_l, ref_l, rtol=2e-4)
+    # per-member rows (3-D feed of the reference): losses on the bootstrap batch
+    got_lb = tr.losses(xd, td, idx_d, batch, batch).cpu().numpy()
+    np.testing.assert_allclose(got_lb, ref.losses(x[idx], t[idx]), rtol=2e-4)
+
+    _, gs = ref.grads(x[idx], t[idx])
+    tr.step(xd, td, idx_d.data_ptr(), batch, batch)
+    mw, mb = tr.get_moments(0)
+    n = len(ws)
+    for l in range(n):
+        _close(10.0 * mw[l], gs[l].numpy(), 2e-3, 5e-5, f"dW{l}")
+        _close(10.0 * mb[l], gs[n + l].numpy().reshape(mb[l].shape), 2e-3, 5e-5, f"db{l}")
+    vw, _ = tr.get_moments(1)
+    _close(1000.0 * vw[1], gs[1].numpy() ** 2, 5e-3, 1e-6, "v1")
+    assert tr.steps_done == 1
+
+
+@pytest.mark.parametrize("E,I,H,D,loss,batch", CASES[:3])
+def test_several_adam_steps_track_oracle(hip_lib, E, I, H, D, loss, batch):
+    _need_gpu()
+    rng, pe, ref, x, t, ws, bs = _make(E, I, H, D, loss, 500, seed=7 + E)
+    tr = pe._ensure_trainer(batch)
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    w_init = [w.copy() for w in ws]
+    for k in range(6):
+        b = batch if k != 3 else batch - 9     # a ragged batch in the middle (last batch of an epoch)
+        idx = rng.randint(0, x.shape[0], size=(E, b)).astype(np.int32)
+        idx_d = torch.from_numpy(idx).cuda()
+        tr.step(xd, td, idx_d.data_ptr(), b, b)
+        ref.step(x[idx], t[idx])
+    gw, gb = tr.get_weights()
+    for l in range(3):
+        rw = ref.ws[l].numpy()
+        moved = float(np.linalg.norm(rw - w_init[l]))
+        assert float(np.linalg.norm(gw[l] - rw)) <= 3e-2 * moved, (l, moved)
+        rb = ref.bs[l].numpy().reshape(gb[l].shape)
+        assert float(np.linalg.norm(gb[l] - rb)) <= 3e-2 * float(np.linalg.norm(rb - bs[l].reshape(rb.shape))) + 1e-7
+    # the packed images the prediction kernels read follow the masters
+    pe._weights_on_device = True
+    xs = x[:50]
+    if loss == "MSPE":
+        from oracle import refcpu
+        mean, var = pe.predict_ensemble(xs)
+        sc_in = (pe.scaler_in.cached_mu, pe.scaler_in.cached_var)
+        sc_out = (pe.scaler_out.cached_mu, pe.scaler_out.cached_var)
+        rm, rv = refcpu.ens_forward(xs, gw, gb, sc_in, sc_out)
+        np.testing.assert_allclose(mean, rm, rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(var, rv, rtol=2e-3, atol=1e-6)
+
+
+def test_step_is_bitwise_reproducible(hip_lib):
+    """No atomics on the gradient path: two trainers fed the same batches hold identical weights."""
+    _need_gpu()
+    outs = []
+    for rep in range(2):
+        rng, pe, ref, x, t, ws, bs = _make(3, 11, 128, 4, "MSPE", 300, seed=99)
+        tr = pe._ensure_trainer(64)
+        xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+        for k in range(4):
+            idx = torch.from_numpy(rng.randint(0, 300, size=(3, 64)).astype(np.int32)).cuda()
+            tr.step(xd, td, idx.data_ptr(), 64, 64)
+        outs.append(tr.get_weights())
+    for a, b in zip(outs[0][0] + outs[0][1], outs[1][0] + outs[1][1]):
+        np.testing.assert_array_equal(a, b)
+
+
+class _OracleOps:
+    """The numerics behind reftrain.train_loop, on the same data PE.train sees."""
+
+    def __init__(self, ref, x, t, use_scalers):
+        self.ref, self.x, self.t, self.use_scalers = ref, x, t, use_scalers
+        self.sc_in, self.sc_out = reftrain.RunningScaler(x.shape[1]), reftrain.RunningScaler(t.shape[1])
+
+    def fit_scalers(self, rows):
+        if self.use_scalers:
+            self.sc_in.fit(self.x[rows])
+            self.sc_out.fit(self.t[rows])
+            f = lambda s: (s.mu.astype(np.float32), s.var.astype(np.float32))
+            self.ref.set_scalers(f(self.sc_in), f(self.sc_out))
+
+    def train_step(self, rows):
+        self.ref.step(self.x[rows], self.t[rows])
+
+    def holdout_losses(self, rows):
+        E = self.ref.ws[0].shape[0]
+        return self.ref.losses(np.tile(self.x[rows][None], (E, 1, 1)), np.tile(self.t[rows][None], (E, 1, 1)))
+
+
+@pytest.mark.parametrize("loss,D", [("MSPE", 3), ("MSE", 1)])
+def test_pe_train_follows_oracle_loop(hip_lib, loss, D):
+    """PE.train end to end (same numpy RandomState on both sides): epochs, gradient updates, scaler moments,
+    holdout losses and the elite ranking."""
+    _need_gpu()
+    E, I, H = 4, 9, 128
+    # (the scaler moments _make loads are overwritten by the first fit: the running count starts at 0)
+    rng, pe, ref, x, t, ws, bs = _make(E, I, H, D, loss, 700, seed=5, use_scalers=True, lr=1e-3)
+    kw = dict(batch_size=64, max_epochs=6, holdout_ratio=0.2, max_epochs_since_update=5, min_epoch_before_break=2)
+    out = pe.train(x, t, rng=np.random.RandomState(123), **kw)
+    ops = _OracleOps(ref, x, t, True)
+    elites, final, epochs, updates = reftrain.train_loop(ops, x.shape[0], E, pe.num_elites, np.random.RandomState(123), **kw)
+    assert (pe.train_epochs, pe.train_grad_updates) == (epochs, updates)
+    np.testing.assert_allclose(pe.scaler_in.cached_mu, ops.sc_in.mu, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pe.scaler_out.cached_var, ops.sc_out.var, rtol=1e-5, atol=1e-6)
+    got_final = pe._trainer.losses(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(),
+                                   torch.arange(x.shape[0], dtype=torch.int32, device="cuda"), 0, x.shape[0]).cpu().numpy()
+    full = ops.holdout_losses(np.arange(x.shape[0]))
+    np.testing.assert_allclose(got_final, full, rtol=3e-2)
+    srt = np.sort(final)
+    if len(srt) > pe.num_elites and (srt[pe.num_elites] - srt[pe.num_elites - 1]) > 0.05 * srt[pe.num_elites - 1]:
+        assert sorted(pe.elite_inds) == sorted(elites)
+    np.testing.assert_allclose(out[f"{pe.name}/val_loss"], np.sort(final)[:pe.num_elites].mean(), rtol=3e-2)

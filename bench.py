@@ -109,6 +109,44 @@ def time_update(policy, res, n, reps=3):
     return float(np.median(times[1:])), info
 
 
+def time_train_steps(pe, x, t, batch, steps):
+    """Ensemble training: average microseconds of one train_op (forward, loss, backward, weight
+    gradients, Adam) with per-member bootstrap rows of device-resident data."""
+    tr = pe._ensure_trainer(batch)
+    n = int(x.shape[0])
+    E = pe.num_nets
+    idx = torch.randint(0, n, (E, batch * 8), dtype=torch.int32, device=x.device)
+    ws, bs = pe.get_weights()
+    for k in range(3):
+        tr.step(x, t, idx.data_ptr() + 4 * batch * (k % 8), batch * 8, batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        tr.step(x, t, idx.data_ptr() + 4 * batch * (k % 8), batch * 8, batch)
+    torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / steps * 1e6
+    pe.set_weights(ws, bs)        # the timing steps must not leak into the benchmark's ensembles
+    tr.reset_optimizer()
+    return us
+
+
+def cpu_train_baseline(E, I, H, O, loss, batch):
+    """One train_op of the oracle (torch-CPU autograd restatement of the TF graph); microseconds."""
+    from oracle import reftrain
+    rng = np.random.default_rng(3)
+    ws = [(rng.standard_normal(s) * 0.05).astype(np.float32) for s in ((E, I, H), (E, H, H), (E, H, O))]
+    bs = [np.zeros((E, 1, s), np.float32) for s in (H, H, O)]
+    ref = reftrain.EnsembleTrainer(ws, bs, loss_type=loss, decays=(2.5e-7, 5e-7, 1e-6))
+    D = O // 2 if loss == "MSPE" else O
+    x = rng.standard_normal((E, batch, I)).astype(np.float32)
+    t = rng.standard_normal((E, batch, D)).astype(np.float32)
+    ref.step(x, t)
+    t0 = time.perf_counter()
+    for _ in range(2):
+        ref.step(x, t)
+    return (time.perf_counter() - t0) / 2 * 1e6
+
+
 def cpu_update_baseline(w, res, n):
     """One CPO update of the oracle (torch-CPU autograd graph + update_pi) on n samples; ms."""
     from oracle import refupdate
@@ -220,6 +258,14 @@ def main():
     upd_ms_50k, upd_info = time_update(policy, res, n50)
     upd_ms_full, _ = time_update(policy, res, n_full, reps=2)
 
+    # Metric C: ensemble training steps (dynamics model on (obs, act) -> (d_obs, rew); critic on obs -> ret)
+    obs_t, act_t, ret_t = res[0], res[1], res[4]
+    n_tr = min(n_full, 200000)
+    x_dyn = torch.cat([obs_t[:n_tr], act_t[:n_tr]], dim=1).contiguous()
+    t_dyn = torch.cat([0.01 * torch.randn_like(obs_t[:n_tr]), ret_t[:n_tr, None]], dim=1).contiguous()
+    model_us = time_train_steps(env._model, x_dyn, t_dyn, 2048, 100)
+    critic_us = time_train_steps(policy.v, obs_t[:n_tr].contiguous(), ret_t[:n_tr, None].contiguous(), 2048, 300)
+
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     comm.all_reduce_max(t)
     dt_max = float(t.item())
@@ -271,10 +317,17 @@ def main():
         out["cpo_update"] = {"unit": "ms", "n_50k": n50, "ms_50k": upd_ms_50k, "n_full": n_full,
                              "ms_full": upd_ms_full, "optim_case": int(upd_info["OptimCase"]),
                              "hvps": 22 if upd_info["OptimCase"] != 4 else 11, "per_rank": True}
+        fl_model = 6.0 * E * 2048 * ((D + A) * H + H * H + H * 2 * (D + 1))
+        out["ensemble_train"] = {"unit": "us/step", "batch": 2048, "model_step_us": model_us,
+                                 "model_tflops": fl_model / model_us / 1e6, "critic_step_us": critic_us,
+                                 "model": f"E={E} {D + A}->{H}->{H}->{2 * (D + 1)} MSPE + Adam",
+                                 "critic": "E=3 obs->128->128->1 MSE + Adam", "per_rank": True}
         if not args.no_cpu_baseline and world == 1:     # the CPU baseline is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(w, task, seconds=args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             out["cpu_baseline"]["cpo_update_ms_50k"] = cpu_update_baseline(w, res, n50)
+            out["cpu_baseline"]["model_train_step_us"] = cpu_train_baseline(E, D + A, H, 2 * (D + 1), "MSPE", 2048)
+            out["cpu_baseline"]["critic_train_step_us"] = cpu_train_baseline(3, D, 128, 1, "MSE", 2048)
         print(json.dumps(out), flush=True)
     comm.barrier()
 

@@ -69,6 +69,16 @@ class CPOPolicy:
         kw = kwargs
         self.hidden_sizes_a = kw.get("a_hidden_layer_sizes", (128, 128))
         self.hidden_sizes_c = kw.get("vf_hidden_layer_sizes", (128, 128))
+        # critic training arguments, cpo_policy.py:332-350
+        self.vf_lr = kw.get("vf_lr", 1e-4)
+        self.vf_epochs = kw.get("vf_epochs", 10)
+        self.vf_batch_size = kw.get("vf_batch_size", 64)
+        self.vf_holdout = 0.1
+        self.vf_train_kwargs = dict(batch_size=self.vf_batch_size, min_epoch_before_break=self.vf_epochs,
+                                    max_epochs=self.vf_epochs, holdout_ratio=self.vf_holdout)
+        self.vf_decay = kw.get("vf_decay", 1e-6)
+        if kw.get("vf_clipping", False):
+            raise NotImplementedError("vf_clipping is off in every shipped config")
         self.vf_ensemble = kw.get("vf_ensemble_size", 5)
         self.vf_elites = kw.get("vf_elites", 3)
         self.vf_activation = kw.get("vf_activation", "ReLU")
@@ -96,7 +106,8 @@ class CPOPolicy:
         self.ops = PolicyOps(self.obs_dim, self.act_dim, self.actor.hidden, self.device, comm=self.comm)
         common = dict(hidden_dims=self.hidden_sizes_c, num_networks=self.vf_ensemble,
                       num_elites=self.vf_elites, loss="MSE", activation="swish",
-                      use_scaler_in=True, use_scaler_out=True, device=self.device)
+                      use_scaler_in=True, use_scaler_out=True, device=self.device, lr=self.vf_lr,
+                      decay=self.vf_decay)
         self.v = PE(self.obs_dim, 1, name="VEnsemble", **common)
         self.vc = PE(self.obs_dim, 1, name="VCEnsemble", **common)
         # pi_info placeholders' shapes (network/ac_network.py:113,120; algorithms/cmbpo.py:94)
@@ -157,11 +168,14 @@ class CPOPolicy:
         return info
 
     def run_diagnostics(self, buf_inputs):
-        """cpo_policy.py:739-754 without the critic losses (critic training is SURVEY §8f row N2)."""
+        """cpo_policy.py:739-754: actor measures and both critic validation losses."""
         self._sync_ops()
         self._bind(buf_inputs)
         m = self.agent.measures(self.ops)
-        return dict(LossPi=m["LossPi"], SurrCost=m["SurrCost"], Entropy=m["Entropy"])
+        out = dict(LossPi=m["LossPi"], SurrCost=m["SurrCost"], Entropy=m["Entropy"])
+        if self.v.finalized and self.vc.finalized:
+            out.update(self.compute_v_losses(buf_inputs))
+        return out
 
     def compute_DKL(self, obs_batch, mu_batch, logstd_batch):
         """cpo_policy.py:837-845: mean KL(current || stored) per archived epoch ([n_epochs, B, .] or 2-D)."""
@@ -178,8 +192,39 @@ class CPOPolicy:
         return one(obs_batch, mu_batch, logstd_batch)
 
     def update_critic(self, buf_inputs, train_vc=True, **kwargs):
-        raise NotImplementedError("critic training (policies/cpo_policy.py:658-731) is SURVEY §8(f) row N2, outside "
-                                  "this path; load critic weights with policy.v.set_weights / policy.vc.set_weights.")
+        """cpo_policy.py:658-698: loss measures, train the return critic (and the cost critic) on the buffer, loss
+        measures again, deltas to the logger.  ``kwargs`` override vf_train_kwargs (and may carry ``rng`` /
+        ``shuffle_on_device`` for PE.train)."""
+        obs, ret, cret = buf_inputs[0], buf_inputs[4], buf_inputs[5]
+        pre = self.compute_v_losses(buf_inputs)
+        self.logger.store(**pre)
+        train_kwargs = self.vf_train_kwargs.copy()
+        train_kwargs.update(kwargs)
+        self.train_vf(obs, ret, **train_kwargs)
+        if train_vc:
+            self.train_vc(obs, cret, **train_kwargs)
+        post = self.compute_v_losses(buf_inputs)
+        deltas = {k + "Delta": post[k] - pre[k] for k in post if k in pre}
+        self.logger.store(**deltas)
+        return dict(pre=pre, post=post)
+
+    def train_vf(self, obs, ret, **kwargs):
+        """cpo_policy.py:700-715"""
+        return self.v.train(obs, ret[:, None], **kwargs)
+
+    def train_vc(self, obs, cret, **kwargs):
+        """cpo_policy.py:717-731"""
+        return self.vc.train(obs, cret[:, None], **kwargs)
+
+    def compute_v_losses(self, buf_inputs, rng=None):
+        """cpo_policy.py:756-774: validation loss of both critics on 5000 rows drawn with replacement."""
+        obs, ret, cret = buf_inputs[0], buf_inputs[4], buf_inputs[5]
+        rand_inds = (np.random if rng is None else rng).randint(0, obs.shape[0], 5000)
+        if isinstance(obs, torch.Tensor):
+            rand_inds = torch.from_numpy(rand_inds).to(obs.device)
+        v_loss = self.v.validate(obs[rand_inds], ret[rand_inds][:, None])
+        vc_loss = self.vc.validate(obs[rand_inds], cret[rand_inds][:, None])
+        return {"Loss" + self.v.name: v_loss, "Loss" + self.vc.name: vc_loss}
 
     # -- acting ----------------------------------------------------------------------------
     def format_obs(self, obs):

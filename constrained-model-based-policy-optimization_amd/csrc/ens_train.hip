@@ -12,7 +12,8 @@
 // One step = training forward (ens_mlp_kernel<HEAD_TRAIN>: raw outputs + exported activations and swish
 // derivatives) -> loss sums -> d(loss)/d(output) -> fused backward chain (two transposed-weight GEMMs, the
 // delta of the middle layer never leaves the CU un-multiplied) -> three weight-gradient GEMMs with the batch as
-// the K dimension (fp32 MFMA, split-K partials, no atomics: the step is bitwise reproducible) -> Adam with the
+// the K dimension (fp32 MFMA, split-K partials, bias gradients as column sums of the same operands; no atomics:
+// the step is bitwise reproducible) -> Adam with the
 // TensorFlow update rule, which also re-packs the new weights into the MFMA layouts the forward / backward
 // kernels read (the master copy stays row-major for checkpoints).
 #include "common.h"
@@ -223,6 +224,11 @@ struct WgradArgs {
   size_t out_member, out_part;
   int ldc, transposed, n_out;  // C[m][n] -> out[m * ldc + n] (transposed: out[n * ldc + m]), n < n_out
   int B, rows_per_wg, n_tiles;
+  // bias gradient of the same layer = column sums of one operand, accumulated next to the MFMAs:
+  // mode 1: columns of Bm (workgroups with mt == 0), mode 2: columns of A (workgroups with nt == 0)
+  float *bias_out;             // [ks][E][bias_member]
+  size_t bias_member, bias_part;
+  int bias_mode, bias_n;
 };
 
 __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(const WgradArgs p) {
@@ -246,6 +252,10 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(const WgradArgs p) {
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+  __shared__ float bred[4][128];
+  const bool sum_b = p.bias_mode == 1 && mt == 0, sum_a = p.bias_mode == 2 && nt == 0;   // workgroup-uniform
+  f32x4 asum = {0.0f, 0.0f, 0.0f, 0.0f};
+  float2 bsum = {0.0f, 0.0f};
 
   // Software pipeline as in mfma_layer: the 8 batch rows of the next block are requested (ping-pong register
   // sets) before the 32 MFMAs of the current one.  Lanes whose columns lie beyond ldb read a valid dummy address:
@@ -268,6 +278,14 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(const WgradArgs p) {
           acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][mi], b[u].x, acc[mi][0], 0, 0, 0);
           acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][mi], b[u].y, acc[mi][1], 0, 0, 0);
         }
+      if (sum_b) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { bsum.x += b[u].x; bsum.y += b[u].y; }
+      }
+      if (sum_a) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) asum += a[u];
+      }
     };
     f32x4 a0[4], a1[4];
     float2 b0[4], b1[4];
@@ -319,8 +337,25 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(const WgradArgs p) {
         __builtin_amdgcn_sched_barrier(0);   // one tile of LDS reads in flight at a time (register budget)
       }
   };
+  if (sum_b) {   // lanes i and i + 32 hold the even / odd batch rows of the same two columns
+    const float x = bsum.x + __shfl_xor(bsum.x, 32, 64), y = bsum.y + __shfl_xor(bsum.y, 32, 64);
+    if (h == 0) { bred[wave][2 * i] = x; bred[wave][2 * i + 1] = y; }
+  }
+  if (sum_a) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float x = asum[c] + __shfl_xor(asum[c], 32, 64);
+      if (h == 0) bred[wave][4 * i + c] = x;
+    }
+  }
   if (wave >= 2) spill(wave - 2);
   __syncthreads();
+  if ((sum_b && tid < 64) || (sum_a && tid < 128)) {
+    const int col = (sum_b ? n0 : m0) + tid;
+    if (col < p.bias_n)
+      p.bias_out[(size_t)blockIdx.y * p.bias_part + (size_t)e * p.bias_member + col] =
+          (bred[0][tid] + bred[1][tid]) + (bred[2][tid] + bred[3][tid]);
+  }
   if (wave < 2) absorb(wave);
   __syncthreads();
   if (wave == 1) spill(0);
@@ -357,21 +392,6 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(const WgradArgs p) {
   }
 }
 
-// bias gradients: column sums of a delta array, fixed summation order
-__global__ __launch_bounds__(kThreads) void colsum_kernel(const float *y, int ld, int n_cols, int B, float *out, int out_ld) {
-  __shared__ float sm[4][64];
-  const int e = blockIdx.y;
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-  float s = 0.0f;
-  if (c < n_cols) {
-    const float *col = y + (size_t)e * B * ld + c;
-    for (int b = rg; b < B; b += 4) s += col[(size_t)b * ld];
-  }
-  sm[rg][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (rg == 0 && c < n_cols) out[(size_t)e * out_ld + c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // Adam (tf.train.AdamOptimizer: m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); w -= lr_t m / (sqrt(v) + eps)) and
 // re-packing of the updated weight into the forward ([n-tile][k-group][lane][4] of W) and backward (same layout
@@ -392,9 +412,9 @@ __device__ __forceinline__ size_t pack_index(int k, int n, int kg) {
   return ((((size_t)(n >> 5) * kg + (k >> 3)) * 64 + ((k >> 2) & 1) * 32 + (n & 31)) << 2) + (k & 3);
 }
 
-__global__ __launch_bounds__(kThreads) void adam_w_kernel(const AdamWArgs p) {
+__device__ __forceinline__ void adam_w(const AdamWArgs &p, unsigned block) {
   const size_t per = (size_t)p.K * p.N;
-  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  const size_t i = (size_t)block * kThreads + threadIdx.x;
   if (i >= per * p.E) return;
   const int e = (int)(i / per);
   const size_t r = i - (size_t)e * per;
@@ -416,20 +436,21 @@ __global__ __launch_bounds__(kThreads) void adam_w_kernel(const AdamWArgs p) {
 
 struct AdamBArgs {
   float *B, *m, *v;
-  const float *g; int g_ld;
+  const float *g; int n_parts; size_t part_stride;   // [n_parts][E][N]
   float *blob; int blob_ld;
   int E, N;
   float lr_t, b1, b2, eps;
   int apply;
 };
 
-__global__ __launch_bounds__(kThreads) void adam_b_kernel(const AdamBArgs p) {
-  const int i = blockIdx.x * kThreads + threadIdx.x;
+__device__ __forceinline__ void adam_b(const AdamBArgs &p, unsigned block) {
+  const int i = block * kThreads + threadIdx.x;
   if (i >= p.E * p.N) return;
   const int e = i / p.N, n = i - e * p.N;
   float w = p.B[i];
   if (p.apply) {
-    const float g = p.g[(size_t)e * p.g_ld + n];
+    float g = 0.0f;
+    for (int s = 0; s < p.n_parts; ++s) g += p.g[(size_t)s * p.part_stride + i];
     float m = p.m[i], v = p.v[i];
     m += (g - m) * (1.0f - p.b1);
     v += (g * g - v) * (1.0f - p.b2);
@@ -437,6 +458,23 @@ __global__ __launch_bounds__(kThreads) void adam_b_kernel(const AdamBArgs p) {
     p.m[i] = m; p.v[i] = v; p.B[i] = w;
   }
   p.blob[(size_t)e * p.blob_ld + n] = w;
+}
+
+// all six parameter tensors in one launch: blocks [first[k], first[k + 1]) belong to tensor k (W0 W1 W2 b0 b1 b2)
+struct AdamAllArgs {
+  AdamWArgs w[3];
+  AdamBArgs b[3];
+  unsigned first[7];
+};
+
+__global__ __launch_bounds__(kThreads) void adam_all_kernel(const AdamAllArgs p) {
+  const unsigned blk = blockIdx.x;
+  if (blk < p.first[1]) adam_w(p.w[0], blk);
+  else if (blk < p.first[2]) adam_w(p.w[1], blk - p.first[1]);
+  else if (blk < p.first[3]) adam_w(p.w[2], blk - p.first[2]);
+  else if (blk < p.first[4]) adam_b(p.b[0], blk - p.first[3]);
+  else if (blk < p.first[5]) adam_b(p.b[1], blk - p.first[4]);
+  else adam_b(p.b[2], blk - p.first[5]);
 }
 
 }  // namespace
@@ -474,13 +512,19 @@ int launch_wgrad(cmbpo_trainer *t, int layer, int batch, hipStream_t s) {
   if (layer == 0) {         // dW0[k][n] = sum_b x[b][k] d1[b][n]: computed as (d1^T x), written transposed
     a.A = t->d1; a.lda = H; a.Bm = t->x; a.ldb = t->IP; n_cols = t->IP;
     a.ldc = H; a.transposed = 1; a.n_out = t->I;
+    a.bias_mode = 2; a.bias_n = H;          // db0 = column sums of d1
   } else if (layer == 1) {  // dW1 = h1^T d2
     a.A = t->h1; a.lda = H; a.Bm = t->d2; a.ldb = H; n_cols = H;
     a.ldc = H; a.transposed = 0; a.n_out = H;
+    a.bias_mode = 1; a.bias_n = H;          // db1 = column sums of d2
   } else {                  // dW2 = h2^T d3
     a.A = t->h2; a.lda = H; a.Bm = t->d3; a.ldb = t->OPk; n_cols = t->OPk;
     a.ldc = t->O; a.transposed = 0; a.n_out = t->O;
+    a.bias_mode = 1; a.bias_n = t->O;       // db2 = column sums of d3
   }
+  a.bias_out = t->dB[layer];
+  a.bias_member = t->bsize[layer] / t->E;
+  a.bias_part = t->bsize[layer];
   a.out = t->parts[layer];
   a.out_member = t->wsize[layer] / t->E;
   a.out_part = t->wsize[layer];
@@ -526,8 +570,10 @@ int launch_update(cmbpo_trainer *t, int apply, float lr_t, hipStream_t s) {
   const size_t b_stride[3] = {0, (size_t)(H / 32) * (H / 8) * 256, (size_t)(H / 32) * (t->OPk / 8) * 256};
   float *blob_b[3] = {m->d_blob + m->off_b0, m->d_blob + m->off_b1, m->d_blob + m->off_b2};
   const int blob_ld[3] = {H, H, m->o_tiles * 32};
+  AdamAllArgs all{};
+  unsigned blocks = 0;
   for (int l = 0; l < 3; ++l) {
-    AdamWArgs a{};
+    AdamWArgs &a = all.w[l];
     a.W = t->W[l]; a.m = t->mW[l]; a.v = t->vW[l];
     a.parts = t->parts[l]; a.n_parts = t->ks[l]; a.part_stride = t->wsize[l];
     a.decay = t->decay[l];
@@ -535,16 +581,21 @@ int launch_update(cmbpo_trainer *t, int apply, float lr_t, hipStream_t s) {
     a.fwd = fwd[l]; a.f_kg = f_kg[l]; a.f_stride = f_stride[l];
     a.bwd = bwd[l]; a.b_kg = b_kg[l]; a.b_stride = b_stride[l];
     a.lr_t = lr_t; a.b1 = t->b1; a.b2 = t->b2; a.eps = t->eps; a.apply = apply;
-    const size_t n = t->wsize[l];
-    hipLaunchKernelGGL(adam_w_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, a);
-    AdamBArgs b{};
+    all.first[l] = blocks;
+    blocks += (unsigned)((t->wsize[l] + kThreads - 1) / kThreads);
+  }
+  for (int l = 0; l < 3; ++l) {
+    AdamBArgs &b = all.b[l];
     b.B = t->Bv[l]; b.m = t->mB[l]; b.v = t->vB[l];
-    b.g = t->dB[l]; b.g_ld = Ns[l];
+    b.g = t->dB[l]; b.n_parts = t->ks[l]; b.part_stride = t->bsize[l];
     b.blob = blob_b[l]; b.blob_ld = blob_ld[l];
     b.E = E; b.N = Ns[l];
     b.lr_t = lr_t; b.b1 = t->b1; b.b2 = t->b2; b.eps = t->eps; b.apply = apply;
-    hipLaunchKernelGGL(adam_b_kernel, dim3(cmbpo_ceil_div(E * Ns[l], kThreads)), dim3(kThreads), 0, s, b);
+    all.first[3 + l] = blocks;
+    blocks += (unsigned)cmbpo_ceil_div(E * Ns[l], kThreads);
   }
+  all.first[6] = blocks;
+  hipLaunchKernelGGL(adam_all_kernel, dim3(blocks), dim3(kThreads), 0, s, all);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }
@@ -606,7 +657,7 @@ extern "C" int cmbpo_trainer_create(cmbpo_trainer_t **out, cmbpo_mlp_t *m, int m
   for (int l = 0; l < 3; ++l) {
     oW[l] = take(t->wsize[l]); omW[l] = take(t->wsize[l]); ovW[l] = take(t->wsize[l]);
     oB[l] = take(t->bsize[l]); omB[l] = take(t->bsize[l]); ovB[l] = take(t->bsize[l]);
-    oP[l] = take(t->wsize[l] * t->ks[l]); odB[l] = take(t->bsize[l]);
+    oP[l] = take(t->wsize[l] * t->ks[l]); odB[l] = take(t->bsize[l] * t->ks[l]);
   }
   const size_t owpb1 = take((size_t)E * (H / 32) * (H / 8) * 256);
   const size_t owpb2 = take((size_t)E * (H / 32) * (t->OPk / 8) * 256);
@@ -771,8 +822,8 @@ extern "C" int cmbpo_trainer_step(cmbpo_trainer_t *t, const float *d_inputs, int
 
   LossArgs l{};
   fill_loss_args(t, l, d_targets, d_idx, idx_stride, batch);
-  CMBPO_HIP_CHECK(hipMemsetAsync(t->sums, 0, 3 * (size_t)E * sizeof(double), s));
   if (t->prob) {   // the MSE gradient needs no batch statistic
+    CMBPO_HIP_CHECK(hipMemsetAsync(t->sums, 0, 3 * (size_t)E * sizeof(double), s));
     const int gx = min(cmbpo_ceil_div(batch * t->D, kThreads), 64);
     hipLaunchKernelGGL(loss_sums_kernel, dim3(gx, E), dim3(kThreads), 0, s, l);
   }
@@ -794,10 +845,6 @@ extern "C" int cmbpo_trainer_step(cmbpo_trainer_t *t, const float *d_inputs, int
     rc = launch_wgrad(t, layer, batch, s);
     if (rc != CMBPO_OK) return rc;
   }
-  hipLaunchKernelGGL(colsum_kernel, dim3(H / 64, E), dim3(kThreads), 0, s, t->d1, H, H, batch, t->dB[0], H);
-  hipLaunchKernelGGL(colsum_kernel, dim3(H / 64, E), dim3(kThreads), 0, s, t->d2, H, H, batch, t->dB[1], H);
-  hipLaunchKernelGGL(colsum_kernel, dim3(cmbpo_ceil_div(t->O, 64), E), dim3(kThreads), 0, s, t->d3, t->OPk, t->O, batch,
-                     t->dB[2], t->O);
   CMBPO_HIP_CHECK(hipGetLastError());
 
   t->step += 1;

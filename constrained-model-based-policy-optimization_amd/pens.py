@@ -488,17 +488,22 @@ class PE(TrainControl):
         if not self.finalized:
             self.init_weights()
         ws, bs = self.get_weights()
-        # a larger batch than any seen before re-creates the step buffers; the Adam moments restart (the shipped
-        # configs train every ensemble with one fixed batch size)
+        # a larger batch than any seen before re-creates the step buffers; weights and Adam state move over
+        old = self._trainer
+        state = None if old is None else (old.get_moments(0), old.get_moments(1), old.steps_done)
         self._trainer = EnsembleTrainer(self.mlp, max(int(batch_size), 32), self.lr, self.decays)
         self._trainer.set_weights(ws, bs)
+        if state is not None:
+            (mw, mb), (vw, vb), steps = state
+            self._trainer.set_moments(0, mw, mb, steps)
+            self._trainer.set_moments(1, vw, vb, steps)
         return self._trainer
 
     def validate(self, inputs, targets):
         """pe.py:440-451: mean `self.loss` of the num_elites best members on (inputs, targets)."""
         x, _ = _to_dev(inputs, self.device)
         t, _ = _to_dev(targets, self.device)
-        tr = self._ensure_trainer(min(x.shape[0], 4096))
+        tr = self._trainer if self._trainer is not None else self._ensure_trainer(min(x.shape[0], 4096))
         idx = torch.arange(x.shape[0], dtype=torch.int32, device=self.device)
         losses = tr.losses(x, t, idx, 0, x.shape[0]).cpu().numpy()
         return np.sort(losses)[:self.num_elites].mean()

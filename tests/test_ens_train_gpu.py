@@ -187,3 +187,44 @@ def test_pe_train_follows_oracle_loop(hip_lib, loss, D):
     if len(srt) > pe.num_elites and (srt[pe.num_elites] - srt[pe.num_elites - 1]) > 0.05 * srt[pe.num_elites - 1]:
         assert sorted(pe.elite_inds) == sorted(elites)
     np.testing.assert_allclose(out[f"{pe.name}/val_loss"], np.sort(final)[:pe.num_elites].mean(), rtol=3e-2)
+
+
+def test_update_critic_trains_both_critics(hip_lib):
+    """CPOPolicy.update_critic (policies/cpo_policy.py:658-698): both critics fit their returns, the logger gets the
+    loss measures and their deltas, the rollout-side predict() reads the trained weights."""
+    _need_gpu()
+    from cmbpo_amd.cpo_policy import CPOPolicy
+
+    class _Space:
+        def __init__(self, d):
+            self.shape = (d,)
+
+    D, A, n = 12, 3, 6000
+    rng = np.random.RandomState(3)
+    pol = CPOPolicy(_Space(D), _Space(A), a_hidden_layer_sizes=(128, 128), vf_hidden_layer_sizes=(128, 128),
+                    vf_ensemble_size=3, vf_elites=2, vf_activation="swish", vf_loss="MSE", device="cuda:0",
+                    vf_lr=3e-3, vf_epochs=6, vf_batch_size=256, max_path_length=10)
+    pol.v.init_weights(rng)
+    pol.vc.init_weights(rng)
+    obs = rng.standard_normal((n, D)).astype(np.float32)
+    ret = (np.sin(obs[:, 0]) + 0.5 * obs[:, 1] + 3.0).astype(np.float32)
+    cret = (np.abs(obs[:, 2]) * 2.0).astype(np.float32)
+    z = np.zeros(n, np.float32)
+    buf = [obs, np.zeros((n, A), np.float32), z, z, ret, cret, z, z, z, z, np.zeros((n, A), np.float32),
+           np.zeros((n, A), np.float32)]
+    out = pol.update_critic(buf, rng=rng)
+    assert out["post"]["LossVEnsemble"] < 0.5 * out["pre"]["LossVEnsemble"]
+    assert out["post"]["LossVCEnsemble"] < 0.5 * out["pre"]["LossVCEnsemble"]
+    st = pol.logger.stored
+    for k in ("LossVEnsemble", "LossVCEnsemble", "LossVEnsembleDelta", "LossVCEnsembleDelta"):
+        assert k in st
+    assert pol.v.train_epochs == 6 and pol.v.train_grad_updates == 6 * int(np.ceil(5400 / 256))
+    assert len(pol.v.elite_inds) == 2
+    # get_v reads the packed weights the trainer maintains: mean over members, de-normalised by the fitted scaler
+    from oracle import refcpu
+    ws, bs = pol.v.get_weights()
+    sc_in = (pol.v.scaler_in.cached_mu, pol.v.scaler_in.cached_var)
+    sc_out = (pol.v.scaler_out.cached_mu, pol.v.scaler_out.cached_var)
+    ref = refcpu.ens_predict_mean(obs[:200], ws, bs, sc_in, sc_out)[:, 0]
+    np.testing.assert_allclose(pol.get_v(obs[:200]), ref, rtol=2e-4, atol=2e-4)
+    assert float(np.mean((pol.get_v(obs) - ret) ** 2)) < 0.2 * float(np.var(ret))

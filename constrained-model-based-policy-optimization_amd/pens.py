@@ -26,7 +26,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, checkpoint
 
 _ACTS = {"swish": _lib.ACT_SWISH, "tanh": _lib.ACT_TANH}
 
@@ -332,6 +332,7 @@ class PE(TrainControl):
                              "(512,512) dynamics, (128,128) critics); got %r" % (hidden_dims,))
         self.name = name
         self.loss_type = loss
+        self.activation = activation
         self.num_nets, self.num_elites = int(num_networks), int(num_elites)
         self._in_dim, self._out_dim = int(in_dim), int(out_dim)
         self.hidden = hidden_dims[0]
@@ -430,6 +431,31 @@ class PE(TrainControl):
     def reset(self):
         """pe.py:405-411: re-draw the layer variables (the optimizer state is NOT reset there either)."""
         self.init_weights()
+
+    # -- checkpoints (pe.py:736-783; file format in checkpoint.py) ----------------
+    def save(self, savedir, timestep):
+        """Writes <name>_<timestep>.nns / .mat exactly as the reference does (structure + nonoptvars + optvars)."""
+        if not self.finalized:
+            raise RuntimeError()
+        ws, bs = self.get_weights()
+        sc = lambda s: (s.cached_mu, s.cached_var)
+        return checkpoint.save_ensemble(
+            savedir, self.name, timestep, ws, bs, self.activation, self.decays, self.is_probabilistic,
+            sc(self.scaler_in) if self.use_scaler_in else None, sc(self.scaler_out) if self.use_scaler_out else None)
+
+    def load(self, model_dir, timestep=None):
+        """Loads <name>[_<timestep>].nns / .mat (the reference reads <name>.nns / <name>.mat, pe.py:355-361,766-783)."""
+        ck = checkpoint.load_ensemble(model_dir, self.name, timestep, self.use_scaler_in, self.use_scaler_out)
+        O = 2 * self._out_dim if self.is_probabilistic else self._out_dim
+        want = [(self._in_dim, self.hidden), (self.hidden, self.hidden), (self.hidden, O)]
+        got = [tuple(w.shape[1:]) for w in ck["weights"]]
+        if got != want or any(w.shape[0] != self.num_nets for w in ck["weights"]):
+            raise ValueError("checkpoint structure %r x %d does not match this ensemble %r x %d"
+                             % (got, ck["weights"][0].shape[0], want, self.num_nets))
+        if ck["layers"][0]["activation"] != self.activation:
+            raise ValueError("checkpoint activation %r != %r" % (ck["layers"][0]["activation"], self.activation))
+        self.set_weights(ck["weights"], ck["biases"], ck["scaler_in"], ck["scaler_out"])
+        return ck
 
     # -- prediction --------------------------------------------------------------
     def predict_ensemble(self, inputs, act=None, row_idx=None, out=None):

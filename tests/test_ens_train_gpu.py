@@ -228,3 +228,26 @@ def test_update_critic_trains_both_critics(hip_lib):
     ref = refcpu.ens_predict_mean(obs[:200], ws, bs, sc_in, sc_out)[:, 0]
     np.testing.assert_allclose(pol.get_v(obs[:200]), ref, rtol=2e-4, atol=2e-4)
     assert float(np.mean((pol.get_v(obs) - ret) ** 2)) < 0.2 * float(np.var(ret))
+
+
+def test_checkpoint_round_trip_through_device(hip_lib, tmp_path):
+    """PE.save after training steps -> PE.load into a fresh ensemble: same masters, same predictions."""
+    _need_gpu()
+    rng, pe, ref, x, t, ws, bs = _make(3, 11, 128, 4, "MSPE", 300, seed=21)
+    tr = pe._ensure_trainer(64)
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    for k in range(3):
+        idx = torch.from_numpy(rng.randint(0, 300, size=(3, 64)).astype(np.int32)).cuda()
+        tr.step(xd, td, idx.data_ptr(), 64, 64)
+    pe._weights_on_device = True
+    pe.save(str(tmp_path), 7)
+    from cmbpo_amd.pens import PE
+    pe2 = PE(11, 4, name="T", hidden_dims=(128, 128), num_networks=3, num_elites=1, loss="MSPE", use_scaler_in=True,
+             use_scaler_out=True, device="cuda:0")
+    pe2.load(str(tmp_path), 7)
+    for a, b in zip(pe.get_weights()[0] + pe.get_weights()[1], pe2.get_weights()[0] + pe2.get_weights()[1]):
+        np.testing.assert_array_equal(a, b)
+    m1, v1 = pe.predict_ensemble(x[:40])
+    m2, v2 = pe2.predict_ensemble(x[:40])
+    np.testing.assert_array_equal(m1, m2)
+    np.testing.assert_array_equal(v1, v2)

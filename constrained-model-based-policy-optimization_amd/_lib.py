@@ -120,6 +120,7 @@ SIGNATURES.update({
     "cmbpo_trainer_set_moments": (_i, [_p, _i] + [_p] * 6 + [C.c_long, _p]),
     "cmbpo_mlp_set_scalers": (_i, [_p] * 6),
     "cmbpo_trainer_step": (_i, [_p, _p, _i, _p, _i, _p, _i, _i, _p]),
+    "cmbpo_trainer_epoch": (_i, [_p, _p, _i, _p, _i, _p, _i, _i, _i, _p]),
     "cmbpo_trainer_losses": (_i, [_p, _p, _i, _p, _i, _p, _i, _i, _p, _p]),
     "cmbpo_trainer_steps_done": (C.c_long, [_p]),
 })

@@ -19,6 +19,7 @@
 #include "common.h"
 #include "ens_mlp_internal.h"
 #include "mfma_tile.h"
+#include "row_tile.h"
 
 #include <math.h>
 #include <new>
@@ -393,6 +394,286 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(const WgradArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Fused step for the small deterministic ensembles (critics: 128-wide, MSE, output width <= 32).  At these sizes
+// the separate kernels above are latency chains of a few microseconds each, so the whole gradient -- gather,
+// scaler, forward, output delta, backward chain, weight and bias gradients -- runs in ONE kernel built like the
+// policy-update kernel (policy_update.hip): tiles of 32 rows on the MFMA columns, every activation image once in
+// LDS in the row layout, swish' kept in registers between the forward and the backward epilogue, weight gradients
+// as MFMAs over the tile's rows accumulated in registers across the workgroup's tiles.  Each workgroup writes its
+// partial gradient with plain stores (Adam adds the partials in a fixed order: still no atomics).
+// ------------------------------------------------------------------------------------------------------------
+struct FusedArgs {
+  const f32x4 *F0, *F1, *F2, *B1, *B2;
+  size_t sF0, sF1, sF2, sB1, sB2;          // per member, float4 units
+  const float *b0, *b1, *b2;
+  int b2_ld;
+  const float *in_mu, *in_sig, *out_mu, *out_sig;
+  const float *inputs, *targets;
+  const int32_t *idx;
+  int idx_stride;
+  int E, I, IP, kg0, O, kga, B;
+  float *pW[3], *pB[3];                    // partial buffers [workgroup][E][...]
+  size_t sW[3], sB[3];                     // floats per partial
+};
+
+// One workgroup per CU (the grid is at most 32 x E workgroups) buys a 512-register budget, and that changes the
+// shape of the kernel: with one 32-column n-tile per wave a k-group is only 4 MFMAs (256 cycles), far too short to
+// hide an L2 round trip behind a one-group prefetch, so the member's weights are fetched ONCE at kernel start -- the
+// forward fragments (~110 registers per lane) stay in registers for every tile, W1^T (64 KB) and the biases sit in LDS
+// next to the 76 KB of activation images -- and the rows and targets of the next tile are gathered into registers
+// while the current tile computes.
+template <int KG>
+__device__ __forceinline__ void load_frags(f32x4 (&a)[KG], const f32x4 *wp, int kg, int lane) {
+#pragma unroll
+  for (int g = 0; g < KG; ++g) {
+    a[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (g < kg) a[g] = wp[(size_t)g * 64 + lane];
+  }
+}
+
+// acc += A(frags) * B, B = rows [sample][stride] in LDS, k-groups [0, kg) starting at column k0
+template <int KG>
+__device__ __forceinline__ void mfma_frags(const f32x4 (&a)[KG], int kg, const float *rows, int stride, int k0, int lane,
+                                           f32x16 &acc) {
+  const float *rl = rows + (lane & 31) * stride + 4 * (lane >> 5) + k0;
+#pragma unroll
+  for (int g = 0; g < KG; ++g) {
+    if (g < kg) {
+      const f32x4 b = *reinterpret_cast<const f32x4 *>(rl + 8 * g);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][s], b[s], acc, 0, 0, 0);
+    }
+  }
+}
+
+template <int N_IT>
+__global__ __launch_bounds__(kThreads, 1) void fused_mse_step_kernel(const FusedArgs p) {
+  constexpr int HID = 128, KGH = HID / 8, RS = HID + 4, RED_LD = BB + 1;
+  constexpr int KG0 = 4 * N_IT;             // k-groups of the (padded) input width
+  extern __shared__ f32x4 smem4[];
+  float *sm = reinterpret_cast<float *>(smem4);
+  const int XS = p.IP + 4;
+  float *xR = sm;                       // [BB][XS]
+  float *h1R = xR + BB * XS;            // [BB][RS]
+  float *h2R = h1R + BB * RS;
+  float *u1R = h2R + BB * RS;           // split-K reduction image of the output layer, then delta1
+  float *u2R = u1R + BB * RS;           // delta2
+  float *wR = u2R + BB * RS;            // [BB][36] output delta
+  float *biasL = wR + BB * 36;          // [b0 | b1] of the member
+  f32x4 *bk1L = reinterpret_cast<f32x4 *>(biasL + 2 * HID);   // W1^T fragments [n-tile][k-group][lane] (64 KB)
+  float *red = u1R, *d1R = u1R, *d2R = u2R;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int e = blockIdx.y;
+  const int n_tiles = (p.B + BB - 1) / BB;
+  const float inv_bd = 1.0f / ((float)p.B * (float)p.O);
+
+  // ---- the member's weights, once: forward fragments in registers, W1^T and the biases in LDS -----------------
+  f32x4 f0[KG0], f1[KGH], f2[4], bk2[4];
+  load_frags<KG0>(f0, p.F0 + e * p.sF0 + (size_t)wave * p.kg0 * 64, p.kg0, lane);
+  load_frags<KGH>(f1, p.F1 + e * p.sF1 + (size_t)wave * KGH * 64, KGH, lane);
+  load_frags<4>(f2, p.F2 + e * p.sF2 + (size_t)wave * 4 * 64, 4, lane);        // K split: k-groups 4w .. 4w + 3
+  load_frags<4>(bk2, p.B2 + e * p.sB2 + (size_t)wave * p.kga * 64, p.kga, lane);
+  {
+    const f32x4 *src = p.B1 + e * p.sB1;
+    f32x4 tmp[KGH];
+#pragma unroll
+    for (int u = 0; u < KGH; ++u) tmp[u] = src[tid + u * kThreads];     // 4 n-tiles x 16 k-groups x 64 lanes
+#pragma unroll
+    for (int u = 0; u < KGH; ++u) bk1L[tid + u * kThreads] = tmp[u];
+    biasL[tid] = (tid < HID) ? p.b0[(size_t)e * HID + tid] : p.b1[(size_t)e * HID + tid - HID];
+  }
+  const f32x4 *bk1W = bk1L + (size_t)wave * KGH * 64 + lane;
+  const float *b2 = p.b2 + (size_t)e * p.b2_ld;
+
+  f32x16 gW1[4], gW0[N_IT], gW2;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) zero(gW1[t]);
+#pragma unroll
+  for (int t = 0; t < N_IT; ++t) zero(gW0[t]);
+  zero(gW2);
+  float gbias = 0.0f;                       // thread n < 128: db1[n]; thread 128 + n: db0[n]
+  float gb2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+  for (int i = tid; i < BB * 36; i += kThreads) wR[i] = 0.0f;   // padded delta columns stay zero
+
+  // gather (and scale) this thread's share of a tile's rows / targets into registers
+  float xn[KG0], tn[4];
+  auto gather = [&](int tile) {
+    const int row0 = tile * BB;
+#pragma unroll
+    for (int u = 0; u < KG0; ++u) {
+      const int i = tid + u * kThreads;
+      xn[u] = 0.0f;
+      if (i < p.IP * BB) {
+        const int b = i / p.IP, k = i - b * p.IP;
+        const int r = row0 + b;
+        if (r < p.B && k < p.I) {
+          const int src = p.idx ? p.idx[(size_t)e * p.idx_stride + r] : r;
+          float v = p.inputs[(size_t)src * p.I + k];
+          if (p.in_mu) v = (v - p.in_mu[k]) / p.in_sig[k];
+          xn[u] = v;
+        }
+      }
+    }
+    const int er = row0 + (tid & 31);
+    const int src = (er < p.B) ? (p.idx ? p.idx[(size_t)e * p.idx_stride + er] : er) : -1;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int a = (tid >> 5) + 8 * it;
+      tn[it] = 0.0f;
+      if (a < p.O && src >= 0) {
+        float t = p.targets[(size_t)src * p.O + a];
+        if (p.out_mu) t = (t - p.out_mu[a]) / p.out_sig[a];
+        tn[it] = t;
+      }
+    }
+  };
+  if ((int)blockIdx.x < n_tiles) gather(blockIdx.x);
+  __syncthreads();
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int row0 = tile * BB;
+#pragma unroll
+    for (int u = 0; u < KG0; ++u) {
+      const int i = tid + u * kThreads;
+      if (i < p.IP * BB) {
+        const int b = i / p.IP, k = i - b * p.IP;
+        xR[b * XS + k] = xn[u];
+      }
+    }
+    float tc[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) tc[it] = tn[it];
+    __syncthreads();
+    if (tile + (int)gridDim.x < n_tiles) gather(tile + gridDim.x);   // in flight under this tile's chain
+    // ---- forward -------------------------------------------------------------------------------------------
+    f32x16 acc = load_bias(biasL, wave * 32, lane), g1, g2;
+    mfma_frags<KG0>(f0, p.kg0, xR, XS, 0, lane, acc);
+    {
+      f32x16 hv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float z = acc[r], sg = 1.0f / (1.0f + __expf(-z));
+        hv[r] = z * sg;
+        g1[r] = sg * (1.0f + z * (1.0f - sg));
+      }
+      store_tile_R(hv, wave * 32, h1R, RS, lane);
+    }
+    __syncthreads();
+    acc = load_bias(biasL + HID, wave * 32, lane);
+    mfma_frags<KGH>(f1, KGH, h1R, RS, 0, lane, acc);
+    {
+      f32x16 hv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float z = acc[r], sg = 1.0f / (1.0f + __expf(-z));
+        hv[r] = z * sg;
+        g2[r] = sg * (1.0f + z * (1.0f - sg));
+      }
+      store_tile_R(hv, wave * 32, h2R, RS, lane);
+    }
+    __syncthreads();
+    zero(acc);                            // output layer: K split over the 4 waves
+    mfma_frags<4>(f2, 4, h2R, RS, wave * 32, lane, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int a = (r & 3) + 8 * (r >> 2) + 4 * h;
+      red[(wave * 32 + a) * RED_LD + j] = acc[r];
+    }
+    __syncthreads();
+    // ---- output delta: d(sum_e mean 0.5 (o - t)^2) / d o = (o - t) / (B O), pe.py:911-919 ------------------
+    {
+      const int eb = tid & 31;
+      const bool valid = row0 + eb < p.B;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int a = (tid >> 5) + 8 * it;
+        if (a < p.O) {
+          float m = red[(0 * 32 + a) * RED_LD + eb];
+          m += red[(1 * 32 + a) * RED_LD + eb];
+          m += red[(2 * 32 + a) * RED_LD + eb];
+          m += red[(3 * 32 + a) * RED_LD + eb];
+          m += b2[a];
+          const float cot = valid ? (m - tc[it]) * inv_bd : 0.0f;
+          wR[eb * 36 + a] = cot;
+          gb2p[it] += cot;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- backward: delta2 = (W2 d3) g2 ; delta1 = (W1 delta2) g1 -----------------------------------------
+    zero(acc);
+    mfma_frags<4>(bk2, p.kga, wR, 36, 0, lane, acc);
+    {
+      f32x16 o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = g2[r] * acc[r];
+      store_tile_R(o, wave * 32, d2R, RS, lane);
+    }
+    __syncthreads();
+    zero(acc);
+    {
+      const float *rl = d2R + j * RS + 4 * h;
+#pragma unroll
+      for (int g = 0; g < KGH; ++g) {
+        const f32x4 a = bk1W[g * 64], b = *reinterpret_cast<const f32x4 *>(rl + 8 * g);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], b[s2], acc, 0, 0, 0);
+      }
+    }
+    {
+      f32x16 o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = g1[r] * acc[r];
+      store_tile_R(o, wave * 32, d1R, RS, lane);     // the reduction image is dead (barrier after the delta phase)
+    }
+    __syncthreads();
+    // ---- weight gradients: K = the tile's rows -----------------------------------------------------------
+#pragma unroll
+    for (int J = 0; J < 4; ++J) wgrad_tile(gW1[J], h1R, RS, wave * 32, d2R, RS, J * 32, lane);
+#pragma unroll
+    for (int t = 0; t < N_IT; ++t) wgrad_tile(gW0[t], xR, XS, 32 * t, d1R, RS, wave * 32, lane);
+    wgrad_tile(gW2, h2R, RS, wave * 32, wR, 36, 0, lane);
+    {
+      const float *img = (tid < HID) ? d2R : d1R;
+      const int n = tid & (HID - 1);
+      float sb = 0.0f;
+#pragma unroll 8
+      for (int b = 0; b < BB; ++b) sb += img[b * RS + n];
+      gbias += sb;
+    }
+    __syncthreads();
+  }
+
+  // ---- this workgroup's partial gradient ----------------------------------------------------------------------
+  const size_t part = blockIdx.x;
+  float *oW0 = p.pW[0] + part * p.sW[0] + (size_t)e * p.I * HID;
+  float *oW1 = p.pW[1] + part * p.sW[1] + (size_t)e * HID * HID;
+  float *oW2 = p.pW[2] + part * p.sW[2] + (size_t)e * HID * p.O;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+    for (int J = 0; J < 4; ++J) oW1[(wave * 32 + row) * HID + J * 32 + j] = gW1[J][r];
+#pragma unroll
+    for (int t = 0; t < N_IT; ++t)
+      if (32 * t + row < p.I) oW0[(32 * t + row) * HID + wave * 32 + j] = gW0[t][r];
+    if (j < p.O) oW2[(wave * 32 + row) * p.O + j] = gW2[r];
+  }
+  {
+    const int l = (tid < HID) ? 1 : 0;
+    p.pB[l][part * p.sB[l] + (size_t)e * HID + (tid & (HID - 1))] = gbias;
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int a = (tid >> 5) + 8 * it;
+    const float sb = half_sum(gb2p[it]);
+    if (a < p.O && (tid & 31) == 0) p.pB[2][part * p.sB[2] + (size_t)e * p.O + a] = sb;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Adam (tf.train.AdamOptimizer: m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); w -= lr_t m / (sqrt(v) + eps)) and
 // re-packing of the updated weight into the forward ([n-tile][k-group][lane][4] of W) and backward (same layout
 // of W^T) MFMA images.
@@ -422,7 +703,8 @@ __device__ __forceinline__ void adam_w(const AdamWArgs &p, unsigned block) {
   float w = p.W[i];
   if (p.apply) {
     float g = 0.0f;
-    for (int s = 0; s < p.n_parts; ++s) g += p.parts[(size_t)s * p.part_stride + i];
+#pragma unroll 8
+    for (int s = 0; s < p.n_parts; ++s) g += p.parts[(size_t)s * p.part_stride + i];   // fixed order: reproducible
     g += p.decay * w;                      // d/dw of decay * l2_loss(w), models/pens/fc.py:167-168
     float m = p.m[i], v = p.v[i];
     m += (g - m) * (1.0f - p.b1);
@@ -450,6 +732,7 @@ __device__ __forceinline__ void adam_b(const AdamBArgs &p, unsigned block) {
   float w = p.B[i];
   if (p.apply) {
     float g = 0.0f;
+#pragma unroll 8
     for (int s = 0; s < p.n_parts; ++s) g += p.g[(size_t)s * p.part_stride + i];
     float m = p.m[i], v = p.v[i];
     m += (g - m) * (1.0f - p.b1);
@@ -488,7 +771,9 @@ struct cmbpo_trainer {
   float lr, b1, b2, eps;
   float decay[3];
   long step;
-  int ks[3];                     // grid K split of the three weight-gradient GEMMs (fixed at max_batch)
+  int ks[3];                     // partial gradients per tensor: the grid K split of the weight-gradient GEMMs
+                                 // (fixed at max_batch), or the workgroups per member of the fused step
+  int fused;                     // 1: fused_mse_step_kernel computes the whole gradient
   float *pool;                   // one allocation
   float *W[3], *Bv[3], *mW[3], *vW[3], *mB[3], *vB[3];
   float *wpb1, *wpb2;
@@ -600,6 +885,55 @@ int launch_update(cmbpo_trainer *t, int apply, float lr_t, hipStream_t s) {
   return CMBPO_OK;
 }
 
+int launch_fused(cmbpo_trainer *t, const float *d_inputs, const float *d_targets, const int32_t *d_idx, int idx_stride,
+                 int batch, hipStream_t s) {
+  cmbpo_mlp *m = t->m;
+  const int H = t->H;
+  FusedArgs a{};
+  a.F0 = reinterpret_cast<const f32x4 *>(m->d_blob + m->off_wp0);
+  a.F1 = reinterpret_cast<const f32x4 *>(m->d_blob + m->off_wp1);
+  a.F2 = reinterpret_cast<const f32x4 *>(m->d_blob + m->off_wp2);
+  a.B1 = reinterpret_cast<const f32x4 *>(t->wpb1);
+  a.B2 = reinterpret_cast<const f32x4 *>(t->wpb2);
+  a.sF0 = (size_t)(H / 32) * (t->IP / 8) * 64; a.sF1 = (size_t)(H / 32) * (H / 8) * 64;
+  a.sF2 = (size_t)m->o_tiles * (H / 8) * 64;
+  a.sB1 = (size_t)(H / 32) * (H / 8) * 64; a.sB2 = (size_t)(H / 32) * (t->OPk / 8) * 64;
+  a.b0 = m->d_blob + m->off_b0; a.b1 = m->d_blob + m->off_b1; a.b2 = m->d_blob + m->off_b2;
+  a.b2_ld = m->o_tiles * 32;
+  a.in_mu = m->has_in_scaler ? m->d_blob + m->off_in_mu : nullptr;
+  a.in_sig = m->has_in_scaler ? m->d_blob + m->off_in_var : nullptr;
+  a.out_mu = m->has_out_scaler ? m->d_blob + m->off_out_mu : nullptr;
+  a.out_sig = m->has_out_scaler ? m->d_blob + m->off_out_var : nullptr;
+  a.inputs = d_inputs; a.targets = d_targets; a.idx = d_idx; a.idx_stride = idx_stride;
+  a.E = t->E; a.I = t->I; a.IP = t->IP; a.kg0 = t->IP / 8; a.O = t->O; a.kga = t->OPk / 8; a.B = batch;
+  for (int l = 0; l < 3; ++l) {
+    a.pW[l] = t->parts[l]; a.sW[l] = t->wsize[l];
+    a.pB[l] = t->dB[l]; a.sB[l] = t->bsize[l];
+  }
+  const size_t lds = ((size_t)32 * (t->IP + 4) + 4 * 32 * 132 + 32 * 36 + 2 * 128) * sizeof(float) + 64 * 1024;
+  const int G = t->ks[0];
+  // every partial slot is written: workgroups beyond the batch's tiles store zeros
+  if (t->IP <= 32) {
+    static bool set1 = false;
+    if (!set1) {
+      CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_mse_step_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+      set1 = true;
+    }
+    hipLaunchKernelGGL(fused_mse_step_kernel<1>, dim3(G, t->E), dim3(kThreads), lds, s, a);
+  } else {
+    static bool set2 = false;
+    if (!set2) {
+      CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fused_mse_step_kernel<2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+      set2 = true;
+    }
+    hipLaunchKernelGGL(fused_mse_step_kernel<2>, dim3(G, t->E), dim3(kThreads), lds, s, a);
+  }
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
 int run_forward(cmbpo_trainer *t, const float *d_inputs, const int32_t *d_idx, int idx_stride, int rows, bool exports,
                 hipStream_t s) {
   MlpKernelArgs a{};
@@ -643,7 +977,16 @@ extern "C" int cmbpo_trainer_create(cmbpo_trainer_t **out, cmbpo_mlp_t *m, int m
   t->bsize[0] = (size_t)E * H; t->bsize[1] = (size_t)E * H; t->bsize[2] = (size_t)E * t->O;
   // grid K split: enough workgroups to cover the chip about twice, at least 8 batch rows per workgroup
   const int n_tiles[3] = {cmbpo_ceil_div(t->IP, 64), H / 64, cmbpo_ceil_div(t->OPk, 64)};
+  t->fused = (H == 128 && !t->prob && t->O <= 32 && t->IP <= 64) ? 1 : 0;
   for (int l = 0; l < 3; ++l) {
+    if (t->fused) {
+      // workgroups per member.  A CU delivers ~0.6 TFLOP/s of fp32 MFMA, i.e. ~6 us for the ~4 MFLOP of one 32-row
+      // tile of a 128-wide net: the step is fastest spread one tile per CU (64 x E workgroups at batch 2048), at the
+      // price of Adam adding up to 64 partial gradients (16 MB of reads, a few us)
+      int g = cmbpo_ceil_div(max_batch, 32);
+      t->ks[l] = g > 64 ? 64 : (g < 1 ? 1 : g);
+      continue;
+    }
     const int wgs = (H / 128) * n_tiles[l] * E;
     int ks = cmbpo_ceil_div(512, wgs);
     const int max_ks = max_batch / 32 < 1 ? 1 : max_batch / 32;
@@ -817,6 +1160,14 @@ extern "C" int cmbpo_trainer_step(cmbpo_trainer_t *t, const float *d_inputs, int
   hipStream_t s = (hipStream_t)stream;
   const int E = t->E, H = t->H;
 
+  if (t->fused) {
+    int rc = launch_fused(t, d_inputs, d_targets, d_idx, idx_stride, batch, s);
+    if (rc != CMBPO_OK) return rc;
+    t->step += 1;
+    const double lr_f = (double)t->lr * sqrt(1.0 - pow((double)t->b2, (double)t->step)) / (1.0 - pow((double)t->b1, (double)t->step));
+    return launch_update(t, 1, (float)lr_f, s);
+  }
+
   int rc = run_forward(t, d_inputs, d_idx, idx_stride, batch, true, s);
   if (rc != CMBPO_OK) return rc;
 
@@ -850,6 +1201,23 @@ extern "C" int cmbpo_trainer_step(cmbpo_trainer_t *t, const float *d_inputs, int
   t->step += 1;
   const double lr_t = (double)t->lr * sqrt(1.0 - pow((double)t->b2, (double)t->step)) / (1.0 - pow((double)t->b1, (double)t->step));
   return launch_update(t, 1, (float)lr_t, s);
+}
+
+// One pass over the bootstrap index lists: ceil(n_rows / batch) train_ops enqueued back to back (the inner loop of
+// PE.train, models/pens/pe.py:541-563), the last one on the ragged remainder.
+extern "C" int cmbpo_trainer_epoch(cmbpo_trainer_t *t, const float *d_inputs, int in_dim, const float *d_targets,
+                                   int target_dim, const int32_t *d_idx, int idx_stride, int n_rows, int batch,
+                                   void *stream) {
+  CMBPO_REQUIRE(t && d_inputs && d_targets && d_idx, "cmbpo_trainer_epoch: NULL argument");
+  CMBPO_REQUIRE(n_rows >= 1 && batch >= 1 && batch <= t->max_batch, "cmbpo_trainer_epoch: n_rows %d / batch %d (max %d)",
+                n_rows, batch, t->max_batch);
+  CMBPO_REQUIRE(idx_stride >= n_rows, "cmbpo_trainer_epoch: idx_stride %d < n_rows %d", idx_stride, n_rows);
+  for (int r0 = 0; r0 < n_rows; r0 += batch) {
+    const int b = min(batch, n_rows - r0);
+    const int rc = cmbpo_trainer_step(t, d_inputs, in_dim, d_targets, target_dim, d_idx + r0, idx_stride, b, stream);
+    if (rc != CMBPO_OK) return rc;
+  }
+  return CMBPO_OK;
 }
 
 extern "C" int cmbpo_trainer_losses(cmbpo_trainer_t *t, const float *d_inputs, int in_dim, const float *d_targets,

@@ -200,6 +200,13 @@ class EnsembleTrainer:
                 self._h, _lib.ptr(inputs), inputs.shape[1], _lib.ptr(targets), targets.shape[1], idx_ptr,
                 int(idx_stride), int(batch), _lib.current_stream()), "cmbpo_trainer_step")
 
+    def epoch(self, inputs, targets, idx, batch):
+        """All minibatches of one epoch over idx[E, n] (int32 device tensor), enqueued in one call."""
+        with torch.cuda.device(self.mlp.device):
+            _lib.check(_lib.lib().cmbpo_trainer_epoch(
+                self._h, _lib.ptr(inputs), inputs.shape[1], _lib.ptr(targets), targets.shape[1], _lib.ptr(idx),
+                int(idx.shape[1]), int(idx.shape[1]), int(batch), _lib.current_stream()), "cmbpo_trainer_epoch")
+
     def losses(self, inputs, targets, idx, idx_stride, n_rows, out=None):
         """`self.loss` per member (device tensor [E]); idx: int32 device tensor of rows (idx_stride 0: shared)."""
         if out is None:
@@ -225,7 +232,7 @@ def _to_dev(x, device):
 class TrainControl:
     """Host control flow of ``PE.train`` (models/pens/pe.py:364-403, 457-646): holdout split, bootstrap indices,
     epoch / minibatch loop, per-epoch shuffle, early stopping on the holdout losses, elite ranking.  The numerics
-    sit behind six hooks (``_begin_train``, ``_begin_epoch``, ``_train_batch``, ``_holdout_losses``,
+    sit behind hooks (``_begin_train``, ``_begin_epoch``, ``_train_batch`` / ``_train_epoch``, ``_holdout_losses``,
     ``_shuffle_on_device``, ``_finish_train``) that :class:`PE` implements with the HIP trainer; the class needs
     ``num_nets``, ``num_elites`` and ``name``."""
 
@@ -256,6 +263,13 @@ class TrainControl:
     def _check_train_args(self, kwargs):
         pass
 
+    def _train_epoch(self, n, batch_size):
+        """The minibatch loop (pe.py:541-563); returns the number of gradient updates."""
+        n_batches = int(np.ceil(n / batch_size))
+        for batch_num in range(n_batches):
+            self._train_batch(batch_num, min(batch_size, n - batch_num * batch_size))
+        return n_batches
+
     def train(self, inputs, targets, batch_size=32, max_epochs=None, max_epochs_since_update=5,
               min_epoch_before_break=0, hide_progress=False, holdout_ratio=0.0, max_logging=5000,
               max_grad_updates=None, timer=None, max_t=None, rng=None, shuffle_on_device=False, **kwargs):
@@ -285,9 +299,7 @@ class TrainControl:
         epoch = -1
         for epoch in epoch_iter:
             self._begin_epoch(idxs)
-            for batch_num in range(int(np.ceil(n / batch_size))):
-                self._train_batch(batch_num, min(batch_size, n - batch_num * batch_size))
-                grad_updates += 1
+            grad_updates += self._train_epoch(n, batch_size)
             # shuffle_rows (pe.py:483-485, :564)
             if shuffle_on_device:
                 idxs = self._shuffle_on_device(idxs)
@@ -582,6 +594,12 @@ class PE(TrainControl):
         n = c["gidx"].shape[1]
         c["tr"].step(c["x"], c["t"], c["gidx"].data_ptr() + 4 * batch_num * c["batch_size"], n, rows)
         self._weights_on_device = True
+
+    def _train_epoch(self, n, batch_size):
+        c = self._ctx
+        c["tr"].epoch(c["x"], c["t"], c["gidx"], batch_size)
+        self._weights_on_device = True
+        return int(np.ceil(n / batch_size))
 
     def _shuffle_on_device(self, idxs):
         if not isinstance(idxs, torch.Tensor):

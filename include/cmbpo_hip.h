@@ -378,6 +378,11 @@ int cmbpo_mlp_set_scalers(cmbpo_mlp_t *m, const float *h_in_mu, const float *h_i
 int cmbpo_trainer_step(cmbpo_trainer_t *t, const float *d_inputs, int in_dim,
                        const float *d_targets, int target_dim, const int32_t *d_idx,
                        int idx_stride, int batch, void *stream);
+/* The minibatch loop of one epoch (pe.py:541-563): ceil(n_rows / batch) train steps on columns
+ * [k * batch, (k + 1) * batch) of the index lists, enqueued without returning to the caller. */
+int cmbpo_trainer_epoch(cmbpo_trainer_t *t, const float *d_inputs, int in_dim,
+                        const float *d_targets, int target_dim, const int32_t *d_idx,
+                        int idx_stride, int n_rows, int batch, void *stream);
 /* sess.run(self.loss) (pe.py:264,582-603,629-635): d_losses[e] = 0.5 * mean over rows and
  * target dims of (mean head - scaled target)^2; idx_stride 0 evaluates every member on the same
  * rows (the tiled holdout set). */

@@ -61,6 +61,8 @@ CASES = [  # E, I, H, D, loss, batch
     (3, 29, 128, 1, "MSE", 77),
     (2, 20, 512, 1, "MSE", 64),
     (4, 8, 128, 3, "MSPE", 32),
+    (3, 45, 128, 2, "MSE", 100),     # fused critic step, two row tiles of W0, two outputs
+    (2, 29, 128, 1, "MSE", 2048),    # fused critic step at the shipped batch size
 ]
 
 

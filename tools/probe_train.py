@@ -31,6 +31,14 @@ def run(E, I, H, D, loss, batch, steps, n=200000):
     fl = 6.0 * E * batch * (I * H + H * H + H * (2 * D if loss == "MSPE" else D))
     print(f"E={E} I={I} H={H} D={D} {loss} batch={batch}: {dt * 1e6:.1f} us/step, {fl / dt / 1e12:.2f} TFLOP/s (3x fwd), "
           f"{E * batch / dt / 1e6:.2f} M member-rows/s")
+    ne = (n // batch) * batch
+    eidx = idx[:, :ne].contiguous()
+    tr.epoch(x, t, eidx, batch)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    tr.epoch(x, t, eidx, batch)
+    torch.cuda.synchronize()
+    print(f"   epoch entry point: {(time.time() - t0) / (ne // batch) * 1e6:.1f} us/step over {ne // batch} steps")
     hold = torch.arange(5000, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
     t0 = time.time()

@@ -123,6 +123,16 @@ class CPOPolicy:
         self.logger = logger
         self.agent.set_logger(logger)
 
+    def log(self):
+        """cpo_policy.py:896-931: the agent's optimisation measures and the policy's own stored keys -> logger row."""
+        self.agent.log()
+        for k in ('LossPi', 'SurrCost', 'SurrAdv', 'Entropy', 'KL', 'LossPiDelta', 'SurrCostDelta', 'SurrAdvDelta',
+                  'Loss' + self.v.name, 'Loss' + self.vc.name, 'Loss' + self.v.name + 'Delta',
+                  'Loss' + self.vc.name + 'Delta'):
+            self.logger.log_tabular(k, average_only=True)
+        self.logger.log_tabular('Penalty', 0)
+        self.logger.log_tabular('PenaltyDelta', 0)
+
     def set_params(self, params):
         """Actor parameters ([W0,b0,W1,b1,W2,b2,log_std] or one flat vector) -> rollout + update handles."""
         self.actor.set_params(params)

@@ -37,6 +37,9 @@ class _NullLogger:
     def store(self, **kw):
         self.stored.update(kw)
 
+    def log_tabular(self, *a, **k):
+        pass
+
 
 def cg(Ax, b, cg_iters=10):
     """Host form of utilities/trust_region.py:32-45 (kept for callers that hold NumPy vectors)."""
@@ -214,6 +217,12 @@ class CPOAgent:
 
     def set_logger(self, logger):
         self.logger = logger
+
+    def log(self):
+        """policies/cpo_policy.py:303-315"""
+        for k in ('Optim_A', 'Optim_B', 'Optim_c', 'Optim_q', 'Optim_r', 'Optim_s', 'Optim_Lam', 'Optim_Nu',
+                  'OptimCase', 'Margin', 'BacktrackIters'):
+            self.logger.log_tabular(k, average_only=True)
 
     def _ent(self, log_std):
         return float(np.sum(np.asarray(log_std, np.float64) + 0.5 * np.log(2 * np.pi * np.e)))   # ac_network.py:57-61

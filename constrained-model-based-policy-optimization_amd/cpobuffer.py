@@ -112,8 +112,9 @@ class CPOBuffer:
         assert self.ptr < self.max_size     # buffer has to have room so you can store
         b, p = self.buf_dict, self.ptr
         b["observations"][p], b["actions"][p], b["next_observations"][p] = obs, act, next_obs
-        b["rewards"][p], b["values"][p], b["costs"][p], b["cvalues"][p] = rew, val, cost, cval
-        b["log_probs"][p], b["terminals"][p], b["epochs"][p] = logp, term, epoch
+        one = lambda x: np.asarray(x).reshape(-1)[0]     # the policy hands over batch-of-one arrays
+        b["rewards"][p], b["values"][p], b["costs"][p], b["cvalues"][p] = one(rew), one(val), one(cost), one(cval)
+        b["log_probs"][p], b["terminals"][p], b["epochs"][p] = one(logp), one(term), epoch
         for k in self.sorted_pi_info_keys:
             self.pi_info_bufs[k][p] = pi_info[k]
         self.ptr += 1

@@ -1,0 +1,100 @@
+"""GPU: the CMBPO trainer loop (algorithms/cmbpo.py:177-486) end to end on a toy environment --
+initial exploration, model fit, dynamics-DKL calibration, Boltzmann start states, imagined rollouts, real sampling,
+model re-training, policy / critic updates on real + imagined samples, diagnostics.  The reference has no test for
+its loop and needs MuJoCo + TensorFlow to run, so this checks structural invariants of one short run, not numbers."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+class _Space:
+    def __init__(self, d):
+        self.shape = (d,)
+
+
+class PointEnv:
+    """2-D point mass with drag: obs = [pos, vel, sin/cos of a clock]; reward = -|pos|; cost 1 outside |x| < 1."""
+
+    def __init__(self, seed=0):
+        self.observation_space, self.action_space = _Space(6), _Space(2)
+        self.rng = np.random.RandomState(seed)
+        self.t = 0
+
+    def _obs(self):
+        return np.concatenate([self.pos, self.vel, [np.sin(0.1 * self.t), np.cos(0.1 * self.t)]]).astype(np.float32)
+
+    def reset(self):
+        self.pos, self.vel, self.t = self.rng.uniform(-0.5, 0.5, 2), np.zeros(2), 0
+        return self._obs()
+
+    def step(self, a):
+        a = np.clip(np.asarray(a, np.float64).reshape(-1)[:2], -1, 1)
+        self.vel = 0.9 * self.vel + 0.1 * a + 0.01 * self.rng.standard_normal(2)
+        self.pos = self.pos + 0.1 * self.vel
+        self.t += 1
+        return self._obs(), -float(np.abs(self.pos).sum()), False, {"cost": float(abs(self.pos[0]) > 1.0)}
+
+    def close(self):
+        pass
+
+
+def test_cmbpo_runs_epochs_end_to_end(hip_lib):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cmbpo_amd.cmbpo import CMBPO, format_samples_for_dyn
+    from cmbpo_amd.cpo_policy import CPOPolicy
+    from cmbpo_amd.cpo_sampler import CpoSampler
+    from cmbpo_amd.cpobuffer import CPOBuffer
+
+    np.random.seed(0)
+    env = PointEnv()
+    T = 40
+    policy = CPOPolicy(env.observation_space, env.action_space, a_hidden_layer_sizes=(128, 128),
+                       vf_hidden_layer_sizes=(128, 128), vf_ensemble_size=3, vf_elites=2, vf_activation="swish",
+                       vf_loss="MSE", vf_lr=1e-3, vf_epochs=2, vf_batch_size=256, device="cuda:0", max_path_length=T,
+                       cost_lim=5.0, target_kl=0.01)
+    rng = np.random.RandomState(1)
+    from cmbpo_amd import synthetic
+    policy.set_params(synthetic.policy_params(np.random.default_rng(2), 6, 2, 128))
+    policy.v.init_weights(rng)
+    policy.vc.init_weights(rng)
+    buf = CPOBuffer(600, 6000, env.observation_space, env.action_space)
+    algo = CMBPO(env, policy, buf, sampler=CpoSampler(max_path_length=T), task="default", n_env_interacts=900,
+                 eval_every_n_steps=1, m_train_freq=100, m_networks=4, m_elites=3, m_hidden_dims=(128, 128),
+                 rollout_batch_size=400, rollout_mode="schedule", rollout_schedule=[0, 1, 4, 4], maxroll=6,
+                 initial_real_samples_per_epoch=150, min_real_samples_per_epoch=100, batch_size_policy=2500,
+                 n_initial_exploration_steps=300, n_epochs=50,
+                 initial_model_train_kwargs=dict(min_epochs=3, max_epochs=6, batch_size=128),
+                 model_train_kwargs=dict(min_epochs=1, max_epochs=2, batch_size=128))
+    p0 = policy.actor.get_flat_params().copy()
+    v0 = [w.copy() for w in policy.v.get_weights()[0]]
+    diags = []
+    for d in algo.train():
+        diags.append(d)
+        if d.get("done") or len(diags) > 20:
+            break
+    assert diags and diags[-1].get("done") is True
+    first = diags[0]
+    for k in ("model/samples_added", "model/n_real_samples", "model/poolm_batch_size", "model/LossPi_m",
+              "model/LossPi_r", "times/epoch_rollout_model", "times/train", "OptimCase", "KL", "RetEpAverage",
+              "LossVEnsemble", "model/DynEns/val_loss"):
+        assert k in first, (k, sorted(first))
+    assert algo._total_timestep >= 900 and algo.policy_epoch >= 2
+    # imagined samples fill (approximately) the policy batch, real samples follow the model's uncertainty
+    assert 0.9 * (2500 - 150) <= first["model/samples_added"] <= 1.1 * 2500
+    assert first["model/n_real_samples"] >= 100
+    # the model was fitted (elites ranked, scalers cached), the policy and the critics moved
+    assert algo._model.finalized and len(algo._model.elite_inds) == 3 and algo._model.scaler_in.fitted
+    assert algo._model.train_grad_updates > 0
+    assert float(np.abs(policy.actor.get_flat_params() - p0).max()) > 0
+    assert any(float(np.abs(a - b).max()) > 0 for a, b in zip(policy.v.get_weights()[0], v0))
+    for k, v in first.items():
+        if isinstance(v, (float, np.floating)):
+            assert np.isfinite(v) or k.startswith("model/max") or "Min" in k or "Max" in k, k
+    # the dynamics data the model trained on: inputs [obs | act], targets [delta obs | reward]
+    arch = buf.get_archive(['observations', 'actions', 'next_observations', 'rewards', 'costs', 'terminals', 'epochs'])
+    x, y = format_samples_for_dyn(arch)
+    assert x.shape[1] == 8 and y.shape[1] == 7 and x.shape[0] == buf.arch_size
+    np.testing.assert_allclose(y[:, :6], arch['next_observations'] - arch['observations'])

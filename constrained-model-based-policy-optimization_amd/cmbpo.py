@@ -61,7 +61,8 @@ class CMBPO:
                  rollout_mode='uncertainty', rollout_schedule=(20, 100, 1, 1), maxroll=80,
                  initial_real_samples_per_epoch=5000, min_real_samples_per_epoch=500, batch_size_policy=25000,
                  n_epochs=int(10e7), n_initial_exploration_steps=0, initial_exploration_policy=None, epoch_length=1000,
-                 model_train_kwargs=None, initial_model_train_kwargs=None, device=None, session=None, **_unused):
+                 model_train_kwargs=None, initial_model_train_kwargs=None, shuffle_on_device=True, device=None,
+                 session=None, **_unused):
         if m_learn_cost:
             raise NotImplementedError("m_learn_cost: the learned cost head is unused by every shipped config")
         # RLAlgorithm.__init__ (algorithms/rl_algorithm.py:22-74)
@@ -96,6 +97,9 @@ class CMBPO:
         self._initial_model_train_kwargs.update(initial_model_train_kwargs or {})
         self._model_train_kwargs = dict(min_epochs=1, max_epochs=10)
         self._model_train_kwargs.update(model_train_kwargs or {})
+        # per-epoch shuffle_rows of PE.train on the GPU (same distribution, other random numbers): the host argsort of
+        # an [E, n] array costs more than the epoch's kernels from n ~ 1e5 on.  False restores the reference's draws.
+        self._shuffle_on_device = bool(shuffle_on_device)
 
         if use_model:
             self._model = build_PE(in_dim=self.obs_dim + self.act_dim, out_dim=self.obs_dim + 1, name='DynEns',
@@ -162,7 +166,8 @@ class CMBPO:
                                                   'terminals', 'epochs'])
         dyn_ins, dyn_outs = format_samples_for_dyn(model_samples, append_r=True, append_c=False)
         return self._model.train(dyn_ins, dyn_outs, batch_size=batch_size, max_epochs=max_epochs,
-                                 min_epoch_before_break=min_epochs, holdout_ratio=0.2, max_t=self._max_model_t)
+                                 min_epoch_before_break=min_epochs, holdout_ratio=0.2, max_t=self._max_model_t,
+                                 shuffle_on_device=self._shuffle_on_device)
 
     def _set_rollout_length(self):
         """algorithms/cmbpo.py:494-512"""
@@ -275,7 +280,8 @@ class CMBPO:
                 train_samples = real_samples
             policy.update_real_c(real_samples)
             policy.update_policy(train_samples)
-            policy.update_critic(train_samples, train_vc=bool((train_samples[-3] > 0).any()))
+            policy.update_critic(train_samples, train_vc=bool((train_samples[-3] > 0).any()),
+                                 shuffle_on_device=self._shuffle_on_device)
             if self._use_model:
                 self.approx_model_batch = self.batch_size_policy - n_real_samples
             self.policy_epoch += 1

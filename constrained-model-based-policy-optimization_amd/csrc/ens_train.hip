@@ -23,6 +23,7 @@
 
 #include <math.h>
 #include <new>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -391,6 +392,181 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(const WgradArgs p) {
       }
     }
   }
+}
+
+// Workgroup-tiled variant for the 512-wide ensembles.  The register-direct kernel above moves (128 + 64) x 4 bytes per
+// 2 x 128 x 64 x 2 flops -- 21 flop/B, i.e. ~7 TB/s of L2 traffic at the MFMA peak, and it measured 52 TFLOP/s on dW1.
+// Here the 4 waves form a WM x WN grid of 128 x 64 wave tiles over the SAME batch rows and share the operands through
+// LDS: per 8-row block the workgroup stages one [8][128 WM] slab of A and one [8][64 WN] slab of B (global -> registers
+// one block ahead -> LDS, double buffered, one barrier per block), every wave reads its fragments back as one
+// ds_read_b128 / ds_read_b64 per row pair.  (2 x 2): 256 x 128 tile, 43 flop/B; (4 x 1): 512 x 64 for the narrow
+// operands of the first / last layer.  No cross-wave reduction: each wave owns its output tile.
+template <int WM, int WN>
+__device__ __forceinline__ void wgrad_lds_body(const WgradArgs &p, f32x4 *slab_mem, int bx, int by, int e) {
+  constexpr int TM = 128 * WM, TN = 64 * WN;
+  constexpr int A4 = 8 * TM / 4, B4 = 8 * TN / 4;          // float4 per slab
+  constexpr int A_PER = A4 / kThreads, B_PER = (B4 + kThreads - 1) / kThreads;
+  f32x4 *slab[2] = {slab_mem, slab_mem + A4 + B4};
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int mt = bx / p.n_tiles, nt = bx - mt * p.n_tiles;
+  const int m0 = mt * TM, n0 = nt * TN;
+  const int start = by * p.rows_per_wg;
+  const int end = min(start + p.rows_per_wg, p.B);
+  const float *Abase = p.A + (size_t)e * p.B * p.lda + m0;
+  const float *Bbase = p.Bm + (size_t)e * p.B * p.ldb + n0;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+  const bool sum_b = p.bias_mode == 1 && mt == 0 && wm == 0, sum_a = p.bias_mode == 2 && nt == 0 && wn == 0;
+  f32x4 asum = {0.0f, 0.0f, 0.0f, 0.0f};
+  float2 bsum = {0.0f, 0.0f};
+
+  // two register staging sets: a slab is requested TWO blocks (~2 x 2048 MFMA cycles) before it is written to LDS --
+  // one block of lead does not cover an L2 miss (the operands stream from HBM / MALL, they are read once per XCD)
+  f32x4 ra0[A_PER], rb0[B_PER], ra1[A_PER], rb1[B_PER];
+  auto fetch = [&](int r0, f32x4 (&ra)[A_PER], f32x4 (&rb)[B_PER]) {
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+      const int q = tid + u * kThreads;
+      const int row = q / (TM / 4), c4 = q - row * (TM / 4);
+      ra[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (r0 + row < end) ra[u] = *reinterpret_cast<const f32x4 *>(Abase + (size_t)(r0 + row) * p.lda + 4 * c4);
+    }
+#pragma unroll
+    for (int u = 0; u < B_PER; ++u) {
+      const int q = tid + u * kThreads;
+      const int row = q / (TN / 4), c4 = q - row * (TN / 4);
+      rb[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (q < B4 && r0 + row < end && n0 + 4 * c4 < p.ldb)
+        rb[u] = *reinterpret_cast<const f32x4 *>(Bbase + (size_t)(r0 + row) * p.ldb + 4 * c4);
+    }
+  };
+  auto stash = [&](int buf, const f32x4 (&ra)[A_PER], const f32x4 (&rb)[B_PER]) {
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) slab[buf][tid + u * kThreads] = ra[u];
+#pragma unroll
+    for (int u = 0; u < B_PER; ++u)
+      if (tid + u * kThreads < B4) slab[buf][A4 + tid + u * kThreads] = rb[u];
+  };
+  auto compute = [&](int buf) {
+    const float *As = reinterpret_cast<const float *>(slab[buf]) + wm * 128 + 4 * i;
+    const float *Bs = reinterpret_cast<const float *>(slab[buf] + A4) + wn * 64 + 2 * i;
+    f32x4 a[4];
+    float2 b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = *reinterpret_cast<const f32x4 *>(As + (2 * u + h) * TM);
+      b[u] = *reinterpret_cast<const float2 *>(Bs + (2 * u + h) * TN);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][mi], b[u].x, acc[mi][0], 0, 0, 0);
+        acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][mi], b[u].y, acc[mi][1], 0, 0, 0);
+      }
+    if (sum_b) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { bsum.x += b[u].x; bsum.y += b[u].y; }
+    }
+    if (sum_a) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) asum += a[u];
+    }
+  };
+
+  if (start < end) {
+    fetch(start, ra0, rb0);
+    if (start + 8 < end) fetch(start + 8, ra1, rb1);
+    stash(0, ra0, rb0);
+    __syncthreads();
+    // even blocks live in slab[0], odd blocks in slab[1]
+#pragma unroll 1
+    for (int r0 = start; r0 < end; r0 += 16) {
+      if (r0 + 16 < end) fetch(r0 + 16, ra0, rb0);
+      compute(0);
+      if (r0 + 8 < end) stash(1, ra1, rb1);
+      __syncthreads();
+      if (r0 + 8 >= end) break;
+      if (r0 + 24 < end) fetch(r0 + 24, ra1, rb1);
+      compute(1);
+      if (r0 + 16 < end) stash(0, ra0, rb0);
+      __syncthreads();
+    }
+  }
+
+  const int m0w = m0 + wm * 128, n0w = n0 + wn * 64;
+  if (sum_b) {
+    const float x = bsum.x + __shfl_xor(bsum.x, 32, 64), y = bsum.y + __shfl_xor(bsum.y, 32, 64);
+    float *dst = p.bias_out + (size_t)by * p.bias_part + (size_t)e * p.bias_member;
+    if (h == 0) {
+      if (n0w + 2 * i < p.bias_n) dst[n0w + 2 * i] = x;
+      if (n0w + 2 * i + 1 < p.bias_n) dst[n0w + 2 * i + 1] = y;
+    }
+  }
+  if (sum_a) {
+    float *dst = p.bias_out + (size_t)by * p.bias_part + (size_t)e * p.bias_member;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float x = asum[c] + __shfl_xor(asum[c], 32, 64);
+      if (h == 0 && m0w + 4 * i + c < p.bias_n) dst[m0w + 4 * i + c] = x;
+    }
+  }
+  float *out = p.out + (size_t)by * p.out_part + (size_t)e * p.out_member;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int irow = (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (!p.transposed) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0w + 4 * irow + mi;
+        const int n = n0w + 2 * i;
+        float *dst = out + (size_t)m * p.ldc + n;
+        if (n + 1 < p.n_out) {
+          if ((p.ldc & 1) == 0) *reinterpret_cast<float2 *>(dst) = float2{acc[mi][0][r], acc[mi][1][r]};
+          else { dst[0] = acc[mi][0][r]; dst[1] = acc[mi][1][r]; }
+        } else if (n < p.n_out) {
+          dst[0] = acc[mi][0][r];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int n = n0w + 2 * i + ni;
+        if (n < p.n_out)
+          *reinterpret_cast<f32x4 *>(out + (size_t)n * p.ldc + m0w + 4 * irow) =
+              f32x4{acc[0][ni][r], acc[1][ni][r], acc[2][ni][r], acc[3][ni][r]};
+      }
+    }
+  }
+}
+
+// All three weight-gradient GEMMs of a 512-wide ensemble in one launch: the square layer's 256 x 128 tiles first, the
+// two narrow layers' 512 x 64 tiles behind them, so the small grids fill the CUs the big one frees instead of each
+// running alone on half of the chip.  Workgroup index -> (layer segment, tile, K split, member).
+struct WgradAllArgs {
+  WgradArgs g[3];          // order of execution: layer 1, layer 0, layer 2
+  int first[4];            // first workgroup of each segment
+  int tiles[3], ks[3];     // tiles per (member, split), K splits
+};
+
+__global__ __launch_bounds__(kThreads, 2) void wgrad_all_kernel(const WgradAllArgs p) {
+  __shared__ f32x4 slab_mem[2 * (8 * 512 / 4 + 8 * 64 / 4)];
+  const int blk = blockIdx.x;
+  const int seg = blk < p.first[1] ? 0 : (blk < p.first[2] ? 1 : 2);
+  int q = blk - p.first[seg];
+  const int bx = q % p.tiles[seg];
+  q /= p.tiles[seg];
+  const int by = q % p.ks[seg], e = q / p.ks[seg];
+  if (seg == 0) wgrad_lds_body<2, 2>(p.g[0], slab_mem, bx, by, e);
+  else wgrad_lds_body<4, 1>(p.g[seg], slab_mem, bx, by, e);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -790,10 +966,49 @@ int wgrad_rows_per_wg(int batch, int ks) {
   return (rows + 7) / 8 * 8;   // 4 waves x an even row count
 }
 
+void fill_wgrad_args(cmbpo_trainer *t, int layer, int batch, WgradArgs &a, int &n_cols);
+
 int launch_wgrad(cmbpo_trainer *t, int layer, int batch, hipStream_t s) {
   WgradArgs a{};
   const int H = t->H;
   int n_cols;
+  fill_wgrad_args(t, layer, batch, a, n_cols);
+  a.n_tiles = cmbpo_ceil_div(n_cols, 64);
+  const size_t lds = 2 * 128 * 64 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad_kernel, dim3((H / 128) * a.n_tiles, t->ks[layer], t->E), dim3(kThreads), lds, s, a);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+// the three GEMMs of a 512-wide ensemble in one launch (wgrad_all_kernel)
+int launch_wgrad_all(cmbpo_trainer *t, int batch, hipStream_t s) {
+  WgradAllArgs all{};
+  const int order[3] = {1, 0, 2};
+  int blocks = 0;
+  for (int k = 0; k < 3; ++k) {
+    const int layer = order[k];
+    int n_cols;
+    fill_wgrad_args(t, layer, batch, all.g[k], n_cols);
+    all.g[k].n_tiles = cmbpo_ceil_div(n_cols, layer == 1 ? 128 : 64);
+    all.tiles[k] = (layer == 1 ? t->H / 256 : t->H / 512) * all.g[k].n_tiles;
+    all.ks[k] = t->ks[layer];
+    all.first[k] = blocks;
+    blocks += all.tiles[k] * all.ks[k] * t->E;
+  }
+  all.first[3] = blocks;
+  hipLaunchKernelGGL(wgrad_all_kernel, dim3(blocks), dim3(kThreads), 0, s, all);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+void fill_wgrad_args(cmbpo_trainer *t, int layer, int batch, WgradArgs &a, int &n_cols) {
+  const int H = t->H;
   if (layer == 0) {         // dW0[k][n] = sum_b x[b][k] d1[b][n]: computed as (d1^T x), written transposed
     a.A = t->d1; a.lda = H; a.Bm = t->x; a.ldb = t->IP; n_cols = t->IP;
     a.ldc = H; a.transposed = 1; a.n_out = t->I;
@@ -815,17 +1030,6 @@ int launch_wgrad(cmbpo_trainer *t, int layer, int batch, hipStream_t s) {
   a.out_part = t->wsize[layer];
   a.B = batch;
   a.rows_per_wg = wgrad_rows_per_wg(batch, t->ks[layer]);
-  a.n_tiles = cmbpo_ceil_div(n_cols, 64);
-  const size_t lds = 2 * 128 * 64 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(wgrad_kernel, dim3((H / 128) * a.n_tiles, t->ks[layer], t->E), dim3(kThreads), lds, s, a);
-  CMBPO_HIP_CHECK(hipGetLastError());
-  return CMBPO_OK;
 }
 
 template <int HID>
@@ -987,8 +1191,12 @@ extern "C" int cmbpo_trainer_create(cmbpo_trainer_t **out, cmbpo_mlp_t *m, int m
       t->ks[l] = g > 64 ? 64 : (g < 1 ? 1 : g);
       continue;
     }
-    const int wgs = (H / 128) * n_tiles[l] * E;
-    int ks = cmbpo_ceil_div(512, wgs);
+    int wgs = (H / 128) * n_tiles[l] * E;
+    if (H == 512) wgs = (l == 1) ? (H / 256) * (H / 128) * E : cmbpo_ceil_div(l == 0 ? t->IP : t->OPk, 64) * E;
+    int ks = (H == 512) ? 512 / wgs : cmbpo_ceil_div(512, wgs);   // 512-wide: one full round of 2 workgroups per CU
+    if (const char *env = getenv("CMBPO_WGRAD_KS")) {   // tuning aid: grid K split of the square layer
+      if (l == 1 && atoi(env) > 0) ks = atoi(env);
+    }
     const int max_ks = max_batch / 32 < 1 ? 1 : max_batch / 32;
     if (ks > max_ks) ks = max_ks;
     if (ks > 16) ks = 16;
@@ -1192,9 +1400,14 @@ extern "C" int cmbpo_trainer_step(cmbpo_trainer_t *t, const float *d_inputs, int
   rc = (H == 512) ? launch_bwd<512>(b, tiles, E, lds, s) : launch_bwd<128>(b, tiles, E, lds, s);
   if (rc != CMBPO_OK) return rc;
 
-  for (int layer = 0; layer < 3; ++layer) {
-    rc = launch_wgrad(t, layer, batch, s);
+  if (H == 512) {
+    rc = launch_wgrad_all(t, batch, s);
     if (rc != CMBPO_OK) return rc;
+  } else {
+    for (int layer = 0; layer < 3; ++layer) {
+      rc = launch_wgrad(t, layer, batch, s);
+      if (rc != CMBPO_OK) return rc;
+    }
   }
   CMBPO_HIP_CHECK(hipGetLastError());
 

@@ -63,13 +63,14 @@ CASES = [  # E, I, H, D, loss, batch
     (4, 8, 128, 3, "MSPE", 32),
     (3, 45, 128, 2, "MSE", 100),     # fused critic step, two row tiles of W0, two outputs
     (2, 29, 128, 1, "MSE", 2048),    # fused critic step at the shipped batch size
+    (7, 37, 512, 30, "MSPE", 2048),  # the dynamics ensemble of the AntSafe config at the shipped batch size
 ]
 
 
 @pytest.mark.parametrize("E,I,H,D,loss,batch", CASES)
 def test_first_step_gradients_and_losses(hip_lib, E, I, H, D, loss, batch):
     _need_gpu()
-    rng, pe, ref, x, t, ws, bs = _make(E, I, H, D, loss, 600, seed=E * 1000 + I)
+    rng, pe, ref, x, t, ws, bs = _make(E, I, H, D, loss, max(600, 2 * batch), seed=E * 1000 + I)
     tr = pe._ensure_trainer(batch)
     idx = rng.randint(0, x.shape[0], size=(E, batch)).astype(np.int32)
     xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
@@ -253,3 +254,27 @@ def test_checkpoint_round_trip_through_device(hip_lib, tmp_path):
     m2, v2 = pe2.predict_ensemble(x[:40])
     np.testing.assert_array_equal(m1, m2)
     np.testing.assert_array_equal(v1, v2)
+
+
+def test_pe_train_edge_cases(hip_lib):
+    """No holdout set (the reference ranks NaN losses: member order kept), a batch larger than the data, a second
+    train() call that continues from the first (Adam state and running scaler moments carried over), tensors in."""
+    _need_gpu()
+    rng, pe, ref, x, t, ws, bs = _make(3, 11, 128, 4, "MSPE", 90, seed=31)
+    out = pe.train(x, t, batch_size=256, max_epochs=3, holdout_ratio=0.0, rng=np.random.RandomState(1))
+    assert pe.train_epochs == 3 and pe.train_grad_updates == 3          # one ragged batch per epoch
+    assert list(pe.elite_inds) == [0]                                   # argsort of NaNs, num_elites = 1
+    assert np.isnan(out["T/val_loss"])
+    steps_before = pe._trainer.steps_done
+    count_before = pe.scaler_in.cached_count
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    out2 = pe.train(xd, td, batch_size=32, max_epochs=2, holdout_ratio=0.25, rng=np.random.RandomState(2),
+                    shuffle_on_device=True)
+    n_train = 90 - int(90 * 0.25)
+    assert pe._trainer.steps_done == steps_before + 2 * int(np.ceil(n_train / 32))
+    assert pe.scaler_in.cached_count == count_before + n_train
+    assert np.isfinite(out2["T/val_loss"])
+    m, v = pe.predict_ensemble(x[:10])
+    assert np.isfinite(m).all() and (v > 0).all()
+    with pytest.raises(NotImplementedError):
+        pe.train(x, t, weights=np.ones(90))

@@ -100,12 +100,14 @@ def time_update(policy, res, n, reps=3):
     times, info = [], None
     for _ in range(reps + 1):
         policy.set_params(p0)
+        policy.ops.n_fvp = 0
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         info = policy.update_policy(buf)
         torch.cuda.synchronize()
         times.append((time.perf_counter() - t0) * 1e3)
     policy.set_params(p0)
+    info = dict(info, n_fvp=policy.ops.n_fvp)
     return float(np.median(times[1:])), info
 
 
@@ -316,7 +318,7 @@ def main():
         }
         out["cpo_update"] = {"unit": "ms", "n_50k": n50, "ms_50k": upd_ms_50k, "n_full": n_full,
                              "ms_full": upd_ms_full, "optim_case": int(upd_info["OptimCase"]),
-                             "hvps": 22 if upd_info["OptimCase"] != 4 else 11, "per_rank": True}
+                             "hvps": int(upd_info["n_fvp"]), "per_rank": True}
         fl_model = 6.0 * E * 2048 * ((D + A) * H + H * H + H * 2 * (D + 1))
         out["ensemble_train"] = {"unit": "us/step", "batch": 2048, "model_step_us": model_us,
                                  "model_tflops": fl_model / model_us / 1e6, "critic_step_us": critic_us,

@@ -152,6 +152,7 @@ class PolicyOps:
 
     def fvp_raw(self, v):
         """self.vec = sum_n J^T M J v (+ log_std diagonal) for the device vector v."""
+        self.n_fvp = getattr(self, "n_fvp", 0) + 1
         _lib.check(_lib.lib().cmbpo_pi_fvp(self._h, C.byref(self.batch), v.data_ptr(), self.vec.data_ptr(), self._s()),
                    "cmbpo_pi_fvp")
         self._reduce(self.vec)

@@ -50,39 +50,6 @@ __device__ __forceinline__ void mfma_layer(const f32x4 *__restrict__ wp,
       else b[bt] = *reinterpret_cast<const f32x4 *>(row_lane + bt * 32 * row_stride + 8 * g);
     }
   };
-  if constexpr (NT == 1 && BT == 1 && DEPTH == 1) {
-    // One n-tile per wave (the 128-wide nets): a k-group is only 4 MFMAs = 256 cycles, so one group of lead does not
-    // cover an L2 hit (~1000 cycles) and the layer runs at the memory latency, not at the MFMA rate.  Four A-fragment
-    // registers form a ring: the fragment of group g + 4 is requested as soon as group g's MFMAs are issued (1024
-    // cycles of lead, twice that with the partner wave interleaved); the LDS operand is read one group ahead.
-    f32x4 ar[4], bq[2];
-    const int n = g1 - g0;
-    auto lda = [&](int g) { return (wp + (size_t)g * 64)[lane]; };
-    auto ldb = [&](int g) {
-      if constexpr (!ROWS) return lds_lane[2 * g * BB];
-      else return *reinterpret_cast<const f32x4 *>(row_lane + 8 * g);
-    };
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (u < n) ar[u] = lda(g0 + u);
-    if (n > 0) bq[0] = ldb(g0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-    for (int g = g0; g < g1; g += 4) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (g + u < g1) {
-          if (g + u + 1 < g1) bq[(u + 1) & 1] = ldb(g + u + 1);
-          const f32x4 a = ar[u], b = bq[u & 1];
-#pragma unroll
-          for (int s = 0; s < 4; ++s) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc[0][0], 0, 0, 0);
-          if (g + u + 4 < g1) ar[u] = lda(g + u + 4);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    return;
-  }
   if constexpr (DEPTH == 2) {
     // two k-groups in flight (three register sets): a lone wave per SIMD issues a block in 1024 cycles while an L2
     // hit under load takes ~1150, so one group of lead is not enough when the partner workgroup is not computing

@@ -12,8 +12,9 @@
 // forward chain (as ens_mlp.hip), then either the JVP chain + Fisher cotangent (FVP) or the loss
 // cotangent (GRAD), then the backward chain with the transposed-packed weights, and finally the
 // weight-gradient products sum_b x[b]^T d[b] as MFMAs whose K dimension is the sample index.  Weight
-// gradients stay in registers across all tiles of the workgroup and are flushed once with float
-// atomics (contiguous 128-B segments); nothing but the batch is read from HBM.
+// gradients stay in registers across all tiles of the workgroup and are written once, as the workgroup's
+// partial vector, which a small kernel adds up in workgroup order (no float atomics: results are bitwise
+// reproducible); nothing but the batch is read from HBM.
 //
 // The FVP is the Gauss-Newton / Fisher form  mean_n J^T diag(1/(var_old+eps)) J v  (+ the log_std
 // diagonal): it equals TF's double back-prop of d_kl whenever mu_old == mu(theta), which holds during
@@ -51,7 +52,9 @@ struct PiArgs {
   int n;
   const float *obs, *act, *adv, *cadv, *logp_old, *cost, *mu_old, *ls_old;
   int which;        // GRAD: 0 -> cotangent of pi_loss (-adv), 1 -> cotangent of surr_cost (+cadv)
-  float *vec;       // [P]  raw sums (not divided by n)
+  float *vec;       // [P]  raw sums (not divided by n), written by reduce_parts_kernel
+  float *part;      // [grid][part_ld] per-workgroup partial sums
+  int part_ld;
   double *sums;     // [8]  n, sum ratio*adv, sum ratio*cadv, sum kl, sum cost
 };
 
@@ -318,28 +321,28 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
     __syncthreads();
   }
 
-  // ---- flush -------------------------------------------------------------------------------------------
+  // ---- flush: this workgroup's partial vector (plain stores; reduce_parts_kernel adds the partials in a fixed order)
   if constexpr (MODE != MODE_EVAL) {
+    float *part = p.part + (size_t)blockIdx.x * p.part_ld;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
-      for (int J = 0; J < 4; ++J)
-        atomicAdd(&p.vec[d.oW1 + (wave * 32 + row) * HID + J * 32 + j], gW1[J][r]);
+      for (int J = 0; J < 4; ++J) part[d.oW1 + (wave * 32 + row) * HID + J * 32 + j] = gW1[J][r];
 #pragma unroll
       for (int t = 0; t < N_IT; ++t)
-        if (32 * t + row < d.D) atomicAdd(&p.vec[d.oW0 + (32 * t + row) * HID + wave * 32 + j], gW0[t][r]);
-      if (j < d.A) atomicAdd(&p.vec[d.oW2 + (wave * 32 + row) * d.A + j], gW2[r]);
+        if (32 * t + row < d.D) part[d.oW0 + (32 * t + row) * HID + wave * 32 + j] = gW0[t][r];
+      if (j < d.A) part[d.oW2 + (wave * 32 + row) * d.A + j] = gW2[r];
     }
-    atomicAdd(&p.vec[(tid < HID ? d.ob1 : d.ob0) + (tid & (HID - 1))], gbias);
+    part[(tid < HID ? d.ob1 : d.ob0) + (tid & (HID - 1))] = gbias;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int a = (tid >> 5) + 8 * it;
       const float sb = half_sum(gb2p[it]), sl = half_sum(glsp[it]);
       if (a < d.A && (tid & 31) == 0) {
-        atomicAdd(&p.vec[d.ob2 + a], sb);
-        if constexpr (MODE == MODE_GRAD) atomicAdd(&p.vec[d.ols + a], sl);
-        else atomicAdd(&p.vec[d.ols + a], sl * p.v.ls[a]);
+        part[d.ob2 + a] = sb;
+        if constexpr (MODE == MODE_GRAD) part[d.ols + a] = sl;
+        else part[d.ols + a] = sl * p.v.ls[a];
       }
     }
   }
@@ -362,11 +365,39 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
   }
 }
 
+// vec[i] = sum over workgroups of part[w][i], in workgroup order: the gradient / Fisher-vector product is bitwise
+// reproducible, and cheaper than 2 n_cu workgroups x P float atomics on the same P addresses (11 M atomics for the
+// 128-wide policy, which dominated the kernel at N = 50 000).
+// One workgroup = 64 columns x 16 partial groups: thread (c, g) adds partials g, g + 16, ... of column c, the 16 group
+// sums are combined through LDS in a fixed tree.
+__global__ __launch_bounds__(1024) void reduce_parts_kernel(const float *part, int part_ld, int n_parts, int P, float *vec) {
+  __shared__ float sm[16][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + c;
+  float s = 0.0f;
+  if (i < P)
+    for (int w = g; w < n_parts; w += 16) s += part[(size_t)w * part_ld + i];
+  sm[g][c] = s;
+  __syncthreads();
+  if (g == 0 && i < P) {
+    float t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = sm[k][c];
+#pragma unroll
+    for (int st = 1; st < 16; st <<= 1)
+#pragma unroll
+      for (int k = 0; k + st < 16; k += 2 * st) t[k] += t[k + st];
+    vec[i] = t[0];
+  }
+}
+
 }  // namespace
 
 struct cmbpo_pi {
   PiDims d;
-  float *blob;       // parameters pack | direction pack | vec [P] | sums (8 doubles)
+  float *blob;       // parameters pack | direction pack
+  float *parts;      // [2 n_cu][part_ld] per-workgroup partial gradients
+  int part_ld;
   size_t pack_floats;
   size_t off_F0, off_F1, off_F2, off_B1, off_B2, off_b0, off_b1, off_b2, off_ls;
   int n_cu;
@@ -429,7 +460,11 @@ int launch_pi_n(cmbpo_pi *h, PiArgs &a, hipStream_t s) {
   const int tiles = cmbpo_ceil_div(a.n, BB);
   const int resident = 2 * h->n_cu;   // two 76.8 KB workgroups per CU
   const int grid = tiles < resident ? tiles : resident;
+  a.part = h->parts; a.part_ld = h->part_ld;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, s, a);
+  if (MODE != MODE_EVAL)
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(cmbpo_ceil_div(h->d.P, 64)), dim3(1024), 0, s, h->parts, h->part_ld, grid,
+                       h->d.P, a.vec);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }
@@ -486,8 +521,12 @@ extern "C" int cmbpo_pi_create(cmbpo_pi_t **out, int obs_dim, int hidden, int ac
     return CMBPO_EHIP;
   }
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (hipMalloc(reinterpret_cast<void **>(&h->blob), 2 * off * sizeof(float)) != hipSuccess) {
+  h->part_ld = (d.P + 63) / 64 * 64;
+  h->parts = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&h->blob), 2 * off * sizeof(float)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&h->parts), (size_t)2 * h->n_cu * h->part_ld * sizeof(float)) != hipSuccess) {
     cmbpo_set_error("cmbpo_pi_create: hipMalloc failed");
+    if (h->blob) (void)hipFree(h->blob);
     delete h;
     return CMBPO_ENOMEM;
   }
@@ -498,6 +537,7 @@ extern "C" int cmbpo_pi_create(cmbpo_pi_t **out, int obs_dim, int hidden, int ac
 extern "C" void cmbpo_pi_destroy(cmbpo_pi_t *h) {
   if (!h) return;
   if (h->blob) (void)hipFree(h->blob);
+  if (h->parts) (void)hipFree(h->parts);
   delete h;
 }
 
@@ -517,7 +557,6 @@ extern "C" int cmbpo_pi_loss_grad(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, int 
   CMBPO_REQUIRE(which == 0 || which == 1, "cmbpo_pi_loss_grad: which must be 0 (pi_loss) or 1 (surr_cost)");
   CMBPO_REQUIRE(b->act && b->adv && b->cadv && b->logp_old && b->cost && d_vec && d_sums, "cmbpo_pi_loss_grad: NULL buffer");
   hipStream_t s = (hipStream_t)stream;
-  CMBPO_HIP_CHECK(hipMemsetAsync(d_vec, 0, (size_t)h->d.P * sizeof(float), s));
   CMBPO_HIP_CHECK(hipMemsetAsync(d_sums, 0, 8 * sizeof(double), s));
   a.which = which; a.vec = d_vec; a.sums = d_sums;
   return launch_pi<MODE_GRAD>(h, a, s);
@@ -529,7 +568,6 @@ extern "C" int cmbpo_pi_fvp(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, const floa
   CMBPO_REQUIRE(b->logstd_old && d_v && d_vec, "cmbpo_pi_fvp: NULL buffer");
   hipStream_t s = (hipStream_t)stream;
   if (int rc = do_pack(h, h->blob + h->pack_floats, d_v, s)) return rc;
-  CMBPO_HIP_CHECK(hipMemsetAsync(d_vec, 0, (size_t)h->d.P * sizeof(float), s));
   a.vec = d_vec; a.sums = nullptr;
   return launch_pi<MODE_FVP>(h, a, s);
 }

@@ -236,6 +236,30 @@ class CPOPolicy:
         vc_loss = self.vc.validate(obs[rand_inds], cret[rand_inds][:, None])
         return {"Loss" + self.v.name: v_loss, "Loss" + self.vc.name: vc_loss}
 
+    # -- checkpoints ---------------------------------------------------------------------
+    def save(self, checkpoint_dir, timestep=0):
+        """Actor parameters as ``policy_<timestep>.npz`` (keys W0 b0 W1 b1 W2 b2 log_std: the variables of the
+        reference's ``pi`` scope in creation order, network/ac_network.py:26-36,104) and both critics in the ensemble
+        format (``PE.save``).  The reference writes a TF SavedModel here (cpo_policy.py:890-894, utilities/logx.py:202-259),
+        which only TensorFlow can read or write; a maintainer dumps ``sess.run(get_vars('pi'))`` into this npz instead."""
+        import os
+        names = ("W0", "b0", "W1", "b1", "W2", "b2", "log_std")
+        path = os.path.join(checkpoint_dir, "policy_%s.npz" % timestep)
+        np.savez(path, **dict(zip(names, self.actor.params)))
+        if self.v.finalized:
+            self.v.save(checkpoint_dir, timestep)
+        if self.vc.finalized:
+            self.vc.save(checkpoint_dir, timestep)
+        return path
+
+    def load(self, checkpoint_dir, timestep=0):
+        import os
+        z = np.load(os.path.join(checkpoint_dir, "policy_%s.npz" % timestep))
+        self.set_params([z[k] for k in ("W0", "b0", "W1", "b1", "W2", "b2", "log_std")])
+        for critic in (self.v, self.vc):
+            if os.path.exists(os.path.join(checkpoint_dir, "%s_%s.nns" % (critic.name, timestep))):
+                critic.load(checkpoint_dir, timestep)
+
     # -- acting ----------------------------------------------------------------------------
     def format_obs(self, obs):
         if len(obs.shape) == len(self.obs_space.shape):

@@ -278,3 +278,29 @@ def test_pe_train_edge_cases(hip_lib):
     assert np.isfinite(m).all() and (v > 0).all()
     with pytest.raises(NotImplementedError):
         pe.train(x, t, weights=np.ones(90))
+
+
+def test_policy_checkpoint_round_trip(hip_lib, tmp_path):
+    _need_gpu()
+    from cmbpo_amd import synthetic
+    from cmbpo_amd.cpo_policy import CPOPolicy
+
+    class _Space:
+        def __init__(self, d):
+            self.shape = (d,)
+
+    kw = dict(a_hidden_layer_sizes=(128, 128), vf_hidden_layer_sizes=(128, 128), vf_ensemble_size=3, vf_elites=2,
+              vf_activation="swish", vf_loss="MSE", device="cuda:0", max_path_length=10)
+    pol = CPOPolicy(_Space(9), _Space(3), **kw)
+    pol.set_params(synthetic.policy_params(np.random.default_rng(0), 9, 3, 128))
+    rng = np.random.RandomState(0)
+    pol.v.init_weights(rng)
+    pol.vc.init_weights(rng)
+    pol.save(str(tmp_path), 12)
+    pol2 = CPOPolicy(_Space(9), _Space(3), **kw)
+    pol2.load(str(tmp_path), 12)
+    obs = rng.standard_normal((33, 9)).astype(np.float32)
+    eps = rng.standard_normal((33, 3)).astype(np.float32)
+    a, b = pol.get_action_outs(obs, eps=eps), pol2.get_action_outs(obs, eps=eps)
+    for k in ("pi", "logp_pi", "v", "vc"):
+        np.testing.assert_array_equal(a[k], b[k])

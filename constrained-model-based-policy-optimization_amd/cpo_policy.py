@@ -213,6 +213,9 @@ class CPOPolicy:
         self.train_vf(obs, ret, **train_kwargs)
         if train_vc:
             self.train_vc(obs, cret, **train_kwargs)
+        if self.comm is not None and self.comm.world > 1:    # replicas: rank 0's critics are everyone's
+            self.v.sync_weights(self.comm)
+            self.vc.sync_weights(self.comm)
         post = self.compute_v_losses(buf_inputs)
         deltas = {k + "Delta": post[k] - pre[k] for k in post if k in pre}
         self.logger.store(**deltas)

@@ -42,6 +42,13 @@ class Comm:
                 t.copy_(tmp)
         return t
 
+    def broadcast(self, t, root=0):
+        """In-place broadcast of a contiguous tensor from `root` (trained ensemble weights: training runs as
+        independent replicas, rank 0's result is the one every rank rolls out with)."""
+        if self.world > 1:
+            td.broadcast(t, src=root)
+        return t
+
     def all_reduce_max(self, t):
         if self.world > 1:
             td.all_reduce(t, op=td.ReduceOp.MAX)

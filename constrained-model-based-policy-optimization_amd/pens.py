@@ -440,6 +440,37 @@ class PE(TrainControl):
         ws, bs = self.mlp._keep[:2]
         return [w.copy() for w in ws], [b.reshape(b.shape[0], 1, b.shape[1]).copy() for b in bs]
 
+    def sync_weights(self, comm, root=0):
+        """Multi-GPU jobs train every ensemble as independent replicas (the reference never shards training either);
+        this makes `root`'s weights, scalers and elites the ones every rank uses afterwards."""
+        if comm is None or comm.world == 1:
+            return
+        ws, bs = self.get_weights()
+        parts = [np.asarray(a, np.float32).reshape(-1) for a in ws + bs]
+        if self.use_scaler_in:
+            parts += [self.scaler_in.cached_mu.reshape(-1), self.scaler_in.cached_var.reshape(-1)]
+        if self.use_scaler_out:
+            parts += [self.scaler_out.cached_mu.reshape(-1), self.scaler_out.cached_var.reshape(-1)]
+        parts.append(np.asarray(self._model_inds, np.float32).reshape(-1))
+        flat = torch.from_numpy(np.concatenate(parts).astype(np.float32)).to(self.device)
+        comm.broadcast(flat, root)
+        flat = flat.cpu().numpy()
+        out, off = [], 0
+        for a in parts:
+            out.append(flat[off:off + a.size])
+            off += a.size
+        k = len(ws)
+        new_ws = [o.reshape(w.shape) for o, w in zip(out[:k], ws)]
+        new_bs = [o.reshape(b.shape) for o, b in zip(out[k:2 * k], bs)]
+        i = 2 * k
+        sc_in = sc_out = None
+        if self.use_scaler_in:
+            sc_in, i = (out[i].reshape(1, -1), out[i + 1].reshape(1, -1)), i + 2
+        if self.use_scaler_out:
+            sc_out, i = (out[i].reshape(1, -1), out[i + 1].reshape(1, -1)), i + 2
+        self.set_weights(new_ws, new_bs, sc_in, sc_out)
+        self._model_inds = [int(round(v)) for v in out[i]]
+
     def reset(self):
         """pe.py:405-411: re-draw the layer variables (the optimizer state is NOT reset there either)."""
         self.init_weights()

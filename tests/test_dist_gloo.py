@@ -40,6 +40,9 @@ def _worker(rank, world, port, out_dir):
     rows = comm.all_gather_i32(torch.tensor([10 + rank, rank, 100 * rank, 0], dtype=torch.int32))
     res["rows"] = rows.numpy()
     res["host"] = np.array(comm.all_reduce_host([rank + 1, 2.5]))
+    bc = torch.full((5,), float(rank + 7))
+    comm.broadcast(bc, root=1)                     # trained-weights hand-over (PE.sync_weights)
+    res["bcast"] = bc.numpy()
 
     # 2. budget rule across shards == the unsharded rule (model_sampler.py:282-287)
     rng = np.random.default_rng(0)                 # same stream on both ranks: the global problem
@@ -93,6 +96,7 @@ def test_world2_gloo(tmp_path):
         np.testing.assert_array_equal(r[k]["stats"], want)
         np.testing.assert_array_equal(r[k]["rows"], [[10, 0, 0, 0], [11, 1, 100, 0]])
         np.testing.assert_array_equal(r[k]["host"], [3.0, 5.0])
+        np.testing.assert_array_equal(r[k]["bcast"], [8.0] * 5)
         assert bool(r[k]["budget_ok"]) and int(r[k]["excess"]) > 0
         assert float(r[k]["wmean_err"]) < 1e-12 and float(r[k]["stat_err"]) < 1e-12
 

@@ -281,18 +281,25 @@ class CPOPolicy:
                 e = torch.randn((n, self.act_dim), generator=self._gen, dtype=torch.float32, device=self.device)
             else:
                 e, _ = _to_dev(eps, self.device)
-            f = dict(dtype=torch.float32, device=self.device)
-            out = dict(pi=torch.empty((n, self.act_dim), **f), logp_pi=torch.empty(n, **f),
-                       mu=torch.empty((n, self.act_dim), **f), log_std=torch.empty((n, self.act_dim), **f))
+            # one flat device buffer behind every output: a NumPy caller (the real-environment sampler steps one
+            # observation at a time) pays one device-to-host copy instead of six
+            A = self.act_dim
+            flat = torch.empty(n * (3 * A + 3), dtype=torch.float32, device=self.device)
+            cut = lambda k, shape: flat[k[0]:k[0] + int(np.prod(shape))].view(shape)
+            offs = np.cumsum([0, n * A, n * A, n * A, n, n, n])
+            out = dict(pi=cut(offs[0:1], (n, A)), mu=cut(offs[1:2], (n, A)), log_std=cut(offs[2:3], (n, A)),
+                       logp_pi=cut(offs[3:4], (n,)))
+            v2, vc2 = cut(offs[4:5], (n, 1)), cut(offs[5:6], (n, 1))
             self.actor.forward_device(o, e, out)
-            v = self.v.predict(o)[:, 0]
-            vc = self.vc.predict(o)[:, 0]
-        res = {"pi": out["pi"], "logp_pi": out["logp_pi"],
-               "pi_info": {"mu": out["mu"], "log_std": out["log_std"]}, "v": v, "vc": vc}
+            self.v.predict(o, out=v2)
+            self.vc.predict(o, out=vc2)
         if was_np:
-            res = {k: ({kk: vv.cpu().numpy() for kk, vv in val.items()} if isinstance(val, dict)
-                       else val.cpu().numpy()) for k, val in res.items()}
-        return res
+            h = flat.cpu().numpy()
+            hcut = lambda i, shape: h[offs[i]:offs[i + 1]].reshape(shape)
+            return {"pi": hcut(0, (n, A)), "logp_pi": hcut(3, (n,)),
+                    "pi_info": {"mu": hcut(1, (n, A)), "log_std": hcut(2, (n, A))}, "v": hcut(4, (n,)), "vc": hcut(5, (n,))}
+        return {"pi": out["pi"], "logp_pi": out["logp_pi"], "pi_info": {"mu": out["mu"], "log_std": out["log_std"]},
+                "v": v2[:, 0], "vc": vc2[:, 0]}
 
     def get_v(self, obs):
         o = self.format_obs(obs)

@@ -98,3 +98,42 @@ def test_cmbpo_runs_epochs_end_to_end(hip_lib):
     x, y = format_samples_for_dyn(arch)
     assert x.shape[1] == 8 and y.shape[1] == 7 and x.shape[0] == buf.arch_size
     np.testing.assert_allclose(y[:, :6], arch['next_observations'] - arch['observations'])
+
+
+def test_model_free_loop_and_config_schema(hip_lib):
+    """BASELINE configs[0] (TRPO / CPO model-free plumbing: use_model=False) built from a variant in the reference's
+    config schema (configs/trpo_hcs.py layout) through the from-params registries."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cmbpo_amd.utils import build_experiment
+    np.random.seed(1)
+    env = PointEnv(seed=3)
+    env.max_episode_steps = 40
+    params = {
+        'universe': 'gym', 'task': 'default', 'environment_params': {'normalize_actions': True},
+        'algorithm_params': {'type': 'CMBPO', 'kwargs': {
+            'n_env_interacts': 1500, 'epoch_length': 500, 'eval_every_n_steps': 1, 'n_initial_exploration_steps': 0,
+            'use_model': False, 'batch_size_policy': 500}},
+        'policy_params': {'type': 'cpopolicy', 'kwargs': {
+            'constrain_cost': False, 'a_hidden_layer_sizes': (128, 128), 'vf_lr': 1e-3, 'vf_hidden_layer_sizes': (128, 128),
+            'vf_epochs': 2, 'vf_batch_size': 128, 'vf_ensemble_size': 3, 'vf_elites': 2, 'vf_activation': 'swish',
+            'vf_loss': 'MSE', 'vf_decay': 1e-6, 'vf_clipping': False, 'vf_kl_cliprange': 0.0, 'ent_reg': 0,
+            'target_kl': 0.01, 'cost_lim': 10, 'cost_lam': .5, 'cost_gamma': 0.97, 'lam': .95, 'gamma': 0.99}},
+        'buffer_params': {}, 'sampler_params': {'kwargs': {'render_mode': None}}, 'run_params': {},
+    }
+    algo = build_experiment(params, env, device="cuda:0")
+    from cmbpo_amd import synthetic
+    algo._policy.set_params(synthetic.policy_params(np.random.default_rng(4), 6, 2, 128))
+    rng = np.random.RandomState(5)
+    algo._policy.v.init_weights(rng)
+    algo._policy.vc.init_weights(rng)
+    assert algo._buffer.max_size == 500 and algo.sampler.max_path_length == 40 and algo._policy.max_path_length == 40
+    diags = []
+    for d in algo.train():
+        diags.append(d)
+        if d.get("done") or len(diags) > 10:
+            break
+    assert diags[-1].get("done") is True and algo.policy_epoch == 3
+    assert diags[0]["OptimCase"] == 4                      # unconstrained: TRPO step
+    for k in ("model/LossPi_r", "model/n_real_samples", "KL", "RetEpAverage"):
+        assert k in diags[0], k

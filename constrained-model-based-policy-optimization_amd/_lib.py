@@ -59,7 +59,7 @@ class RolloutStruct(C.Structure):
             "alive", "fin_code", "len",
             "cur_obs", "next_obs", "act_t", "logp_t", "mu_t", "ls_t", "v_t", "vc_t", "v_n", "vc_n",
             "rew_t", "cost_t", "dkl_t", "epv_t", "term_t",
-            "dkl_acc", "path_ret", "path_cost", "path_dyn_var",
+            "dkl_acc", "path_ret", "path_cost", "path_dyn_var", "store_part",
             "obs_buf", "act_buf", "mu_buf", "ls_buf",
             "rew_buf", "val_buf", "cost_buf", "cval_buf", "logp_buf",
             "adv_buf", "ret_buf", "cadv_buf", "cret_buf")]

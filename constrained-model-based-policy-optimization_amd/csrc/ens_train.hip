@@ -13,9 +13,10 @@
 // derivatives) -> loss sums -> d(loss)/d(output) -> fused backward chain (two transposed-weight GEMMs, the
 // delta of the middle layer never leaves the CU un-multiplied) -> three weight-gradient GEMMs with the batch as
 // the K dimension (fp32 MFMA, split-K partials, bias gradients as column sums of the same operands; no atomics:
-// the step is bitwise reproducible) -> Adam with the
-// TensorFlow update rule, which also re-packs the new weights into the MFMA layouts the forward / backward
-// kernels read (the master copy stays row-major for checkpoints).
+// the step is bitwise reproducible; one launch for the 512-wide ensembles) -> Adam with the TensorFlow update
+// rule, which also re-packs the new weights into the MFMA layouts the forward / backward kernels read (the master
+// copy stays row-major for checkpoints).  The 128-wide MSE ensembles (critics) run the whole gradient in one
+// fused kernel instead (fused_mse_step_kernel).
 #include "common.h"
 #include "ens_mlp_internal.h"
 #include "mfma_tile.h"

@@ -263,10 +263,14 @@ __global__ __launch_bounds__(256) void finish_kernel(const cmbpo_rollout_t r, in
 }
 
 // ---- store: transition -> column ptr, sampler accumulators ---------------------------------------
-constexpr int kStoreRows = 256;  // rows per workgroup
+// The copy wants many small workgroups (memory-level parallelism: 196 workgroups of 512 rows moved 54 MB at 0.9 TB/s),
+// the sampler accumulators want few writers (13 contended atomics per workgroup: 1563 workgroups took 170 us).  So a
+// tile is 64 rows -- wave 0 handles the scalar fields and reduces the tile's sums with shuffles -- every workgroup
+// writes its 8 sums to r.store_part, and store_stats_kernel (one workgroup) folds them into iscal / dscal in a fixed
+// order: no atomics, reproducible accumulators.
+constexpr int kStoreRows = 64;
 
 __global__ __launch_bounds__(256) void store_kernel(const cmbpo_rollout_t r) {
-  __shared__ double sm_d[16];
   __shared__ int s_slot[kStoreRows];   // branch slot of each row of the tile, -1: not stored
   const int n = r.iscal[CMBPO_I_N_ALIVE];
   const int tid = threadIdx.x;
@@ -274,9 +278,8 @@ __global__ __launch_bounds__(256) void store_kernel(const cmbpo_rollout_t r) {
   if (row0 >= n) return;
   const size_t B = (size_t)r.B;
   const int D = r.obs_dim, A = r.act_dim;
-  const double dkl_mean = r.dscal[CMBPO_D_DKL_SUM_T] / (double)n;  // np.mean over the rows stepped
-  double a_cnt = 0, a_cost = 0, a_rew = 0, a_v = 0, a_vc = 0, a_epv = 0, a_maxdkl = 0, a_maxret = 0;
-  {
+  if (tid < kStoreRows) {
+    double a_cnt = 0, a_cost = 0, a_rew = 0, a_v = 0, a_vc = 0, a_epv = 0, a_maxdkl = 0, a_maxret = 0;
     const int i = row0 + tid;
     int b = -1;
     if (i < n) {
@@ -304,6 +307,12 @@ __global__ __launch_bounds__(256) void store_kernel(const cmbpo_rollout_t r) {
       a_maxdkl = (double)dk;
       a_maxret = pr;
     }
+    const double v0 = wave_sum(a_cnt), v1 = wave_sum(a_cost), v2 = wave_sum(a_rew), v3 = wave_sum(a_v);
+    const double v4 = wave_sum(a_vc), v5 = wave_sum(a_epv), v6 = wave_max(a_maxdkl), v7 = wave_max(a_maxret);
+    if (tid == 0) {
+      double *dst = r.store_part + (size_t)blockIdx.x * 8;
+      dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3; dst[4] = v4; dst[5] = v5; dst[6] = v6; dst[7] = v7;
+    }
   }
   __syncthreads();
   // vector fields: consecutive threads -> consecutive elements of a row (rows of a dense alive list are
@@ -323,28 +332,42 @@ __global__ __launch_bounds__(256) void store_kernel(const cmbpo_rollout_t r) {
       if (b >= 0) vdst[f][((size_t)r.ptr * B + b) * dim + d] = vsrc[f][(size_t)b * dim + d];
     }
   }
-  const double cnt = block_sum(a_cnt, sm_d);
-  const double cost = block_sum(a_cost, sm_d);
-  const double rew = block_sum(a_rew, sm_d);
-  const double sv = block_sum(a_v, sm_d);
-  const double svc = block_sum(a_vc, sm_d);
-  const double epv = block_sum(a_epv, sm_d);
-  const double mdkl = block_max(a_maxdkl, sm_d);
-  const double mret = block_max(a_maxret, sm_d);
-  if (tid == 0 && cnt > 0.0) {
-    atomicAdd(&r.iscal[CMBPO_I_N_STORED], (int)cnt);
-    atomicAdd(&r.iscal[CMBPO_I_SIZE], (int)cnt);
-    atomicAdd(&r.dscal[CMBPO_D_TOTAL_SAMPLES], cnt);
-    atomicAdd(&r.dscal[CMBPO_D_TOTAL_COST], cost);
-    atomicAdd(&r.dscal[CMBPO_D_TOTAL_REW], rew);
-    atomicAdd(&r.dscal[CMBPO_D_SUM_PATH_RET], rew);
-    atomicAdd(&r.dscal[CMBPO_D_SUM_PATH_COST], cost);
-    atomicAdd(&r.dscal[CMBPO_D_TOTAL_VS], sv);
-    atomicAdd(&r.dscal[CMBPO_D_TOTAL_CVS], svc);
-    atomicAdd(&r.dscal[CMBPO_D_TOTAL_DYN_EP_VAR], epv);
-    atomicAdd(&r.dscal[CMBPO_D_TOTAL_DKL], dkl_mean * cnt);
-    atomic_max_nonneg(&r.dscal[CMBPO_D_MAX_DKL], mdkl);
-    atomic_max_nonneg(&r.dscal[CMBPO_D_MAX_PATH_RETURN], mret);
+}
+
+// fold the per-tile sums of store_kernel into the counters / accumulators (one workgroup, fixed order)
+__global__ __launch_bounds__(256) void store_stats_kernel(const cmbpo_rollout_t r) {
+  __shared__ double sm_d[16];
+  const int n = r.iscal[CMBPO_I_N_ALIVE];
+  const int n_wg = (n + kStoreRows - 1) / kStoreRows;
+  double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int w = threadIdx.x; w < n_wg; w += 256) {
+    const double *src = r.store_part + (size_t)w * 8;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t[k] += src[k];
+    t[6] = fmax(t[6], src[6]);
+    t[7] = fmax(t[7], src[7]);
+  }
+  double s[8];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) s[k] = block_sum(t[k], sm_d);
+  s[6] = block_max(t[6], sm_d);
+  s[7] = block_max(t[7], sm_d);
+  if (threadIdx.x == 0 && s[0] > 0.0) {
+    const double cnt = s[0];
+    const double dkl_mean = r.dscal[CMBPO_D_DKL_SUM_T] / (double)n;  // np.mean over the rows stepped
+    r.iscal[CMBPO_I_N_STORED] += (int)cnt;
+    r.iscal[CMBPO_I_SIZE] += (int)cnt;
+    r.dscal[CMBPO_D_TOTAL_SAMPLES] += cnt;
+    r.dscal[CMBPO_D_TOTAL_COST] += s[1];
+    r.dscal[CMBPO_D_TOTAL_REW] += s[2];
+    r.dscal[CMBPO_D_SUM_PATH_RET] += s[2];
+    r.dscal[CMBPO_D_SUM_PATH_COST] += s[1];
+    r.dscal[CMBPO_D_TOTAL_VS] += s[3];
+    r.dscal[CMBPO_D_TOTAL_CVS] += s[4];
+    r.dscal[CMBPO_D_TOTAL_DYN_EP_VAR] += s[5];
+    r.dscal[CMBPO_D_TOTAL_DKL] += dkl_mean * cnt;
+    r.dscal[CMBPO_D_MAX_DKL] = fmax(r.dscal[CMBPO_D_MAX_DKL], s[6]);
+    r.dscal[CMBPO_D_MAX_PATH_RETURN] = fmax(r.dscal[CMBPO_D_MAX_PATH_RETURN], s[7]);
   }
 }
 
@@ -553,7 +576,9 @@ extern "C" int cmbpo_rollout_store(const cmbpo_rollout_t *r, void *stream) {
   CMBPO_REQUIRE(r->obs_buf && r->act_buf && r->mu_buf && r->ls_buf && r->rew_buf && r->val_buf && r->cost_buf &&
                     r->cval_buf && r->logp_buf,
                 "cmbpo_rollout_store: NULL buffer");
+  CMBPO_REQUIRE(r->store_part != nullptr, "cmbpo_rollout_store: NULL store_part scratch");
   hipLaunchKernelGGL(store_kernel, dim3(cmbpo_ceil_div(r->B, kStoreRows)), dim3(256), 0, (hipStream_t)stream, *r);
+  hipLaunchKernelGGL(store_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *r);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }

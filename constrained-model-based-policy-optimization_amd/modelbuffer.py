@@ -69,6 +69,7 @@ class ModelBuffer:
         t["len"] = torch.empty(B, dtype=torch.int32, device=dev)
         for name in ("dkl_acc", "path_ret", "path_cost", "path_dyn_var"):
             t[name] = torch.empty(B, **d)
+        t["store_part"] = torch.empty(((B + 63) // 64) * 8, **d)
         # per-step values (slot indexed); cur/next and t/n pairs are swapped every step
         for name, dim in (("cur_obs", D), ("next_obs", D), ("act_t", A), ("mu_t", A), ("ls_t", A)):
             t[name] = torch.zeros((B, dim), **f)

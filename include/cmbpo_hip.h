@@ -176,6 +176,7 @@ typedef struct cmbpo_rollout {
   const float *rew_t, *cost_t, *dkl_t, *epv_t; /* [B]                          */
   const uint8_t *term_t;    /* [B]                                             */
   double *dkl_acc, *path_ret, *path_cost, *path_dyn_var; /* [B] (float64 in the reference) */
+  double *store_part;   /* [ceil(B / 64)][8] per-workgroup sampler sums of cmbpo_rollout_store (scratch) */
   /* time-major buffers */
   float *obs_buf, *act_buf, *mu_buf, *ls_buf;             /* [T,B,dim]         */
   float *rew_buf, *val_buf, *cost_buf, *cval_buf, *logp_buf; /* [T,B]          */

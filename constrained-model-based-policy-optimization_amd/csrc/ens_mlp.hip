@@ -361,7 +361,28 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
       // HID = 512 ([32 w, 32 w + 32) for 128) -- its own h2 slice, straight from registers.  One output tile at
       // a time keeps a single 16-register partial live.
       const int j = lane & 31, h = lane >> 5;
-      for (int ot = 0; ot < p.o_tiles; ++ot) {
+      bool valu_out = false;
+      if constexpr (HEAD == CMBPO_HEAD_DETMEAN && BT == 1) {
+        // One output column (the critics): 16 NT fused multiply-adds per lane on the h2 registers instead of a
+        // 32-column MFMA tile of which one column is used (16 NT MFMAs = 1/6 of a 128-wide member's MFMA time).
+        // Column 0 of the packed W2 sits in lanes 0 / 32 of every k-group: a broadcast 16-B load per (t, q).
+        if (p.o_width == 1) {
+          valu_out = true;
+          const f32x4 *w2c = p.wp2 + e * p.wp2_stride + (size_t)(wave * NT * 4) * 64 + h * 32;
+          float partial = 0.0f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 w = w2c[(size_t)(4 * t + q) * 64];
+#pragma unroll
+              for (int s = 0; s < 4; ++s) partial = fmaf(acc[t][0][4 * q + s], w[s], partial);
+            }
+          partial += __shfl_xor(partial, 32, 64);
+          if (h == 0) red[(wave * p.o_tiles * 32) * RED_LD + j] = partial;
+        }
+      }
+      for (int ot = 0; ot < (valu_out ? 0 : p.o_tiles); ++ot) {
         f32x16 part[BT];
 #pragma unroll
         for (int bt = 0; bt < BT; ++bt)

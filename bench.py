@@ -224,7 +224,7 @@ def main():
     from cmbpo_amd.dist import Comm
     _lib.lib()   # fail loudly if the HIP library is missing
 
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     comm = Comm.init_from_env("nccl")

@@ -19,12 +19,25 @@ class Comm:
         self.rank = td.get_rank() if self.enabled else 0
         self.world = td.get_world_size() if self.enabled else 1
         self.device = device
+        # gloo moves host memory: device tensors are staged through the host (rehearsals of the multi-rank path on
+        # fewer GPUs than ranks; the production backend is nccl = RCCL, which takes device tensors directly)
+        self._stage = self.enabled and td.get_backend() == "gloo"
+
+    def _run(self, fn, t):
+        if self._stage and t.is_cuda:
+            h = t.detach().cpu()
+            fn(h)
+            t.copy_(h)
+        else:
+            fn(t)
+        return t
 
     @staticmethod
     def init_from_env(backend=None):
         """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun)."""
         world = int(os.environ.get("WORLD_SIZE", "1"))
         if world > 1 and not td.is_initialized():
+            backend = os.environ.get("CMBPO_DIST_BACKEND", backend)
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -35,10 +48,10 @@ class Comm:
         """In-place SUM of a (device) tensor; a view of a larger tensor is reduced through a copy."""
         if self.world > 1:
             if t.is_contiguous() and t.storage_offset() == 0:
-                td.all_reduce(t, op=td.ReduceOp.SUM)
+                self._run(lambda x: td.all_reduce(x, op=td.ReduceOp.SUM), t)
             else:
                 tmp = t.contiguous().clone()
-                td.all_reduce(tmp, op=td.ReduceOp.SUM)
+                self._run(lambda x: td.all_reduce(x, op=td.ReduceOp.SUM), tmp)
                 t.copy_(tmp)
         return t
 
@@ -46,12 +59,12 @@ class Comm:
         """In-place broadcast of a contiguous tensor from `root` (trained ensemble weights: training runs as
         independent replicas, rank 0's result is the one every rank rolls out with)."""
         if self.world > 1:
-            td.broadcast(t, src=root)
+            self._run(lambda x: td.broadcast(x, src=root), t)
         return t
 
     def all_reduce_max(self, t):
         if self.world > 1:
-            td.all_reduce(t, op=td.ReduceOp.MAX)
+            self._run(lambda x: td.all_reduce(x, op=td.ReduceOp.MAX), t)
         return t
 
     def all_gather_i32(self, row):
@@ -59,7 +72,12 @@ class Comm:
         row = row.contiguous().clone()
         out = torch.empty((self.world, row.numel()), dtype=row.dtype, device=row.device)
         if self.world > 1:
-            td.all_gather_into_tensor(out.view(-1), row)
+            if self._stage and row.is_cuda:
+                h_out, h_row = out.cpu(), row.cpu()
+                td.all_gather_into_tensor(h_out.view(-1), h_row)
+                out.copy_(h_out)
+            else:
+                td.all_gather_into_tensor(out.view(-1), row)
         else:
             out[0] = row
         return out
@@ -68,7 +86,7 @@ class Comm:
         """SUM of a few host scalars (float64)."""
         if self.world == 1:
             return [float(v) for v in values]
-        dev = self.device if self.device is not None else ("cuda" if td.get_backend() == "nccl" else "cpu")
+        dev = "cpu" if self._stage else (self.device if self.device is not None else "cuda")
         t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
         td.all_reduce(t, op=td.ReduceOp.SUM)
         return t.cpu().tolist()

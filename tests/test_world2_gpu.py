@@ -1,0 +1,207 @@
+"""GPU, world_size 2 (both ranks on the one GPU of the box, gloo with host staging): the SHARDED rollout against the
+reference's own single-process traces (golden G5).  Rank k owns a contiguous block of the trace's branches and replays
+its share of the recorded action noise / elite draws; the cross-shard budget rule, the any-alive protocol, the
+count-weighted two-pass advantage statistics of get() and the sampler diagnostics must reproduce the unsharded
+result: masks and sample order bit-exact, values within the single-GPU tolerances.
+
+The production backend is nccl (RCCL) with one GPU per rank; what differs here is only the transport."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+NAMES = ["obs", "act", "adv", "cadv", "ret", "cret", "logp", "val", "cval", "cost", "log_std", "mu"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, name, out_dir):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, GOLD)
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    import cmbpo_amd  # noqa: F401
+    from cmbpo_amd.cpo_policy import CPOPolicy
+    from cmbpo_amd.dist import Comm
+    from cmbpo_amd.fake_env import FakeEnv
+    from cmbpo_amd.model_sampler import ModelSampler
+    from cmbpo_amd.modelbuffer import ModelBuffer
+    from cmbpo_amd.pens import PE
+    from worlds import build_world
+
+    class _Space:
+        def __init__(self, d):
+            self.shape = (d,)
+
+    comm = Comm(device=torch.device("cuda:0"))
+    g = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    task, B, T, hidden = str(g["task"]), int(g["B"]), int(g["T"]), int(g["hidden"])
+    w = build_world(int(g["seed"]), task, hidden, out_scale=float(g["out_scale"]), q_boost=float(g["q_boost"]))
+    cut = B // 2 + 3                                   # unequal contiguous shards
+    lo, hi = (0, cut) if rank == 0 else (cut, B)
+    Bl = hi - lo
+    D, A = w["obs_dim"], w["act_dim"]
+    model = PE(D + A, D + 1, hidden_dims=(hidden, hidden), num_networks=w["ws"][0].shape[0],
+               num_elites=len(w["elites"]), loss="MSPE", use_scaler_in=True, use_scaler_out=True, device="cuda:0")
+    model.set_weights(w["ws"], w["bs"], w["sc_in"], w["sc_out"])
+    model.set_elites(w["elites"])
+    policy = CPOPolicy(_Space(D), _Space(A), a_hidden_layer_sizes=(128, 128), vf_hidden_layer_sizes=(128, 128),
+                       vf_ensemble_size=3, vf_elites=2, vf_activation="swish", vf_loss="MSE", device="cuda:0",
+                       cost_gamma=0.97, cost_lam=0.5, lam=0.95, comm=comm)
+    policy.actor.set_params(w["pol"])
+    policy.v.set_weights(*w["v"])
+    policy.vc.set_weights(*w["vc"])
+
+    class _Env:
+        observation_space, action_space = _Space(D), _Space(A)
+
+    env = FakeEnv(_Env(), task, model, predicts_delta=True, predicts_rew=True, predicts_cost=False)
+    pool = ModelBuffer(Bl, D, A, T, device="cuda:0", comm=comm)
+    pool.initialize(policy.pi_info_shapes, gamma=0.99, lam=0.95, cost_gamma=0.97, cost_lam=0.5)
+    sampler = ModelSampler(max_path_length=T, batch_size=Bl, rollout_mode=str(g["mode"]), comm=comm)
+    sampler.initialize(env, policy, pool)
+    sampler.set_rollout_dkl(float(g["dkl_lim"]))
+    sampler.reset(g["start"][lo:hi])
+    budget = int(g["budget"]) or None
+    alive_before = np.ones(B, bool)
+    ok_masks, ratios = True, []
+    for s in range(len(g["n_rows"])):
+        n = int(g["n_rows"][s])
+        ids = np.flatnonzero(alive_before)
+        assert len(ids) == n
+        mine = (ids >= lo) & (ids < hi)
+        assert pool.n_alive == int(mine.sum())
+        _, _, _, info = sampler.sample(max_samples=budget, eps=g["eps"][s, :n][mine], model_inds=g["inds"][s, :n][mine])
+        ok_masks = ok_masks and bool(np.array_equal(pool.alive_paths, g["alive"][s][lo:hi]))
+        ratios.append(info["alive_ratio"])
+        alive_before = g["alive"][s].astype(bool)
+    diag = sampler.finish_all_paths()
+    res, bdiag = pool.get()
+    out = {"ok_masks": ok_masks, "ratios": np.array(ratios), "local_samples": sampler._host["total_samples"],
+           "batch": bdiag["poolm_batch_size"], "ret_mean": bdiag["poolm_ret_mean"], "cret_mean": bdiag["poolm_cret_mean"]}
+    for k, arr in zip(NAMES, res):
+        out["get_" + k] = arr
+    for k, v in diag.items():
+        out["diag_" + k.replace("/", "__")] = v
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
+    comm.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("name", ["g5_trace_ant_unc", "g5_trace_hopper_budget", "g5_trace_ant_term"])
+def test_sharded_rollout_reproduces_reference_trace(hip_lib, tmp_path, name):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    sys.path.insert(0, HERE)
+    from test_rollout_sampler_gpu import TOL
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, name, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(os.path.join(tmp_path, f"rank{k}.npz")) for k in range(world)]
+    g = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    assert all(bool(x["ok_masks"]) for x in r)                               # alive masks: bit-exact per shard
+    for x in r:
+        np.testing.assert_array_equal(x["ratios"], g["alive_ratio"])         # global alive ratio on every rank
+    assert sum(float(x["local_samples"]) for x in r) == float(g["total_samples"][-1])
+    assert sum(int(x["batch"]) for x in r) == int(g["poolm_batch_size"])
+    for x in r:                                                              # global means on every rank
+        np.testing.assert_allclose(float(x["ret_mean"]), float(g["poolm_ret_mean"]), rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(float(x["cret_mean"]), float(g["poolm_cret_mean"]), rtol=2e-3, atol=2e-4)
+    for k in NAMES:
+        got = np.concatenate([x["get_" + k] for x in r], axis=0)             # contiguous shards: rank order == trace order
+        ref = g["get_" + k]
+        assert got.shape == ref.shape, k
+        if TOL[k] == 0.0:
+            np.testing.assert_array_equal(got, ref, err_msg=k)
+        else:
+            np.testing.assert_allclose(got, ref, rtol=TOL[k], atol=TOL[k], err_msg=k)
+
+
+def _update_setup(seed=21, n=3001, D=29, A=8, T=35):
+    sys.path.insert(0, GOLD)
+    from worlds import make_update_batch
+    rng = np.random.default_rng(seed)
+    params, batch = make_update_batch(rng, n, D, A, 128, 0.3, 1.0, T)
+    z = np.zeros(n, np.float32)
+    buf = [batch["obs"], batch["act"], batch["adv"], batch["cadv"], z, z, batch["logp_old"], z, z, batch["cost"],
+           batch["log_std_old"], batch["mu_old"]]
+    return params, buf, (D, A, T)
+
+
+def _make_policy(D, A, T, comm=None):
+    from cmbpo_amd.cpo_policy import CPOPolicy
+
+    class _Space:
+        def __init__(self, d):
+            self.shape = (d,)
+
+    return CPOPolicy(_Space(D), _Space(A), a_hidden_layer_sizes=(128, 128), vf_hidden_layer_sizes=(128, 128),
+                     vf_ensemble_size=3, vf_elites=2, vf_activation="swish", vf_loss="MSE", device="cuda:0",
+                     constrain_cost=True, cost_lim=10.0, target_kl=0.01, max_path_length=T, comm=comm)
+
+
+def _worker_update(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    import cmbpo_amd  # noqa: F401
+    from cmbpo_amd.dist import Comm
+    comm = Comm(device=torch.device("cuda:0"))
+    params, buf, (D, A, T) = _update_setup()
+    n = buf[0].shape[0]
+    cut = n // 3                                       # unequal shards: the reductions must weight by counts
+    sl = slice(0, cut) if rank == 0 else slice(cut, n)
+    pol = _make_policy(D, A, T, comm)
+    pol.set_params(params)
+    pol.real_c_buffer = [12.0] * 300
+    info = pol.update_policy([x[sl] for x in buf])
+    np.savez(os.path.join(out_dir, f"upd{rank}.npz"), params=pol.actor.get_flat_params(), case=info["OptimCase"],
+             bt=info["BacktrackIters"], lam=float(info["Optim_Lam"]), nu=float(info["Optim_Nu"]), kl=float(pol.logger.stored["KL"]))
+    comm.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_update_matches_single_rank(hip_lib, tmp_path):
+    """update_policy on two unequal shards (count-weighted all-reduce of gradients, Fisher-vector products and
+    line-search sums) == the same update on the whole batch in one process."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_worker_update, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(os.path.join(tmp_path, f"upd{k}.npz")) for k in range(world)]
+    sys.path.insert(0, os.path.dirname(HERE))
+    import cmbpo_amd  # noqa: F401
+    params, buf, (D, A, T) = _update_setup()
+    pol = _make_policy(D, A, T)
+    pol.set_params(params)
+    pol.real_c_buffer = [12.0] * 300
+    info = pol.update_policy(buf)
+    ref = pol.actor.get_flat_params()
+    step = float(np.linalg.norm(ref - params)) + 1e-12
+    np.testing.assert_array_equal(r[0]["params"], r[1]["params"])            # every rank ends on the same parameters
+    for x in r:
+        assert int(x["case"]) == int(info["OptimCase"]) and int(x["bt"]) == int(info["BacktrackIters"])
+        np.testing.assert_allclose(float(x["lam"]), float(info["Optim_Lam"]), rtol=5e-3)
+        np.testing.assert_allclose(float(x["nu"]), float(info["Optim_Nu"]), rtol=5e-3, atol=1e-7)
+        assert float(np.linalg.norm(x["params"] - ref)) <= 5e-3 * step
+        np.testing.assert_allclose(float(x["kl"]), float(pol.logger.stored["KL"]), rtol=2e-2, atol=1e-6)

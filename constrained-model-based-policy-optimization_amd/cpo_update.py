@@ -65,6 +65,7 @@ class PolicyOps:
         self.device = torch.device(device if device is not None else "cuda")
         self.D, self.A = int(obs_dim), int(act_dim)
         self.comm = comm
+        self.use_graph = True       # CG iterations as a cached hipGraph (single-GPU jobs)
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().cmbpo_pi_create(C.byref(self._h), self.D, int(hidden), self.A), "cmbpo_pi_create")
@@ -86,6 +87,7 @@ class PolicyOps:
         h, self._h = getattr(self, "_h", None), None
         if h:
             try:
+                _lib.lib().cmbpo_pi_cg_release(h)
                 _lib.lib().cmbpo_pi_destroy(h)
             except Exception:
                 pass
@@ -166,6 +168,14 @@ class PolicyOps:
     def cg_dev(self, b, x, damping, iters=10):
         """x = cg(Hx, b) (utilities/trust_region.py:32-45), entirely enqueued on the stream."""
         lib, r, p = _lib.lib(), self.work["cg_r"], self.work["cg_p"]
+        if self.comm is None or self.comm.world == 1:
+            # one C call; the iterations after the first replay as a cached hipGraph (no all-reduce to interleave)
+            _lib.check(lib.cmbpo_pi_cg_solve(self._h, C.byref(self.batch), b.data_ptr(), 1.0 / float(self.n_global),
+                                             float(damping), int(iters), x.data_ptr(), r.data_ptr(), p.data_ptr(),
+                                             self.vec.data_ptr(), self.scal.data_ptr(), 1 if self.use_graph else 0,
+                                             self._s()), "cmbpo_pi_cg_solve")
+            self.n_fvp = getattr(self, "n_fvp", 0) + int(iters)
+            return x
         _lib.check(lib.cmbpo_cg_init(self.P, b.data_ptr(), x.data_ptr(), r.data_ptr(), p.data_ptr(),
                                      self.scal.data_ptr(), self._s()), "cmbpo_cg_init")
         inv_n = 1.0 / float(self.n_global)

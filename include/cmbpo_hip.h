@@ -331,6 +331,14 @@ int cmbpo_adv_normalize(int n, float *d_adv, float *d_cadv, double *d_stats, voi
 int cmbpo_cg_init(int P, const float *d_b, float *d_x, float *d_r, float *d_p, double *d_scal, void *stream);
 int cmbpo_cg_step(int P, const float *d_hp_sum, double inv_n, float damping, float *d_x, float *d_r,
                   float *d_p, double *d_scal, void *stream);
+/* The whole solve x = cg(Hx, b) in one call (single-GPU jobs): cg_init, then `iters` times [cmbpo_pi_fvp on direction
+ * d_p into d_vec, cg_step].  With use_graph != 0 the iterations after the first are captured into a hipGraph that is
+ * cached per handle (re-captured when a pointer / size changes); cmbpo_pi_cg_release drops it. */
+int cmbpo_pi_cg_solve(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, const float *d_b, double inv_n, float damping,
+                      int iters, float *d_x, float *d_r, float *d_p, float *d_vec, double *d_scal,
+                      int use_graph, void *stream);
+void cmbpo_pi_cg_release(cmbpo_pi_t *h);
+long cmbpo_pi_cg_graph_launches(void);   /* graph replays so far; -1: stream capture unavailable, eager loop in use */
 /* d_out = a * d_x + b * d_y (d_y may be NULL): Hx = hvp / N + damping v, the step x = (v + nu w) / (lam + eps)
  * (policies/cpo_policy.py:266) and the trial parameters old - step * x (:278). */
 int cmbpo_vec_lincomb(int P, float a, const float *d_x, float b, const float *d_y, float *d_out, void *stream);

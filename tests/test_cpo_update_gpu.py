@@ -148,3 +148,24 @@ def test_update_policy_matches_oracle(hip_lib, name, cost_p, cadv_scale, cost_li
         assert k in st, k
     if ref["accepted"]:
         assert float(st["KL"]) <= 0.01 * 1.05
+
+
+def test_cg_solve_graph_matches_eager_loop(hip_lib):
+    """cmbpo_pi_cg_solve with the hipGraph replay == the same solve with the iterations launched one by one."""
+    _need_gpu()
+    from cmbpo_amd import _lib
+    rng, params, batch, graph, ops = _setup(29, 8, 5000, seed=3)
+    b = torch.from_numpy(rng.standard_normal(params.shape).astype(np.float32)).cuda()
+    outs = []
+    for use_graph in (True, False, True):
+        ops.use_graph = use_graph
+        x = torch.zeros_like(b)
+        ops.cg_dev(b, x, 0.1)
+        outs.append(x.cpu().numpy().copy())
+    np.testing.assert_array_equal(outs[0], outs[1])        # same kernels, same order: bitwise equal
+    np.testing.assert_array_equal(outs[0], outs[2])
+    assert _lib.lib().cmbpo_pi_cg_graph_launches() >= 2    # capture is available on this stack and was replayed
+    # and it is the CG of the oracle's operator
+    ref = refupdate.cg(lambda v: graph.hvp(params, v, 0.1), b.cpu().numpy()) if hasattr(refupdate, "cg") else None
+    if ref is not None:
+        _close(outs[0], ref, rtol=2e-2, arel=2e-3)

@@ -37,3 +37,5 @@ for i in range(reps + 1):
     times.append((time.perf_counter() - t0) * 1e3)
 print(f"N={N} constrained={constrained}: case {info['OptimCase']} backtrack {info['BacktrackIters']} "
       f"update ms: first {times[0]:.2f} median {np.median(times[1:]):.2f} min {min(times[1:]):.2f}")
+from cmbpo_amd import _lib
+print("cg graph launches:", _lib.lib().cmbpo_pi_cg_graph_launches())

@@ -64,6 +64,11 @@ CASES = [  # E, I, H, D, loss, batch
     (3, 45, 128, 2, "MSE", 100),     # fused critic step, two row tiles of W0, two outputs
     (2, 29, 128, 1, "MSE", 2048),    # fused critic step at the shipped batch size
     (7, 37, 512, 30, "MSPE", 2048),  # the dynamics ensemble of the AntSafe config at the shipped batch size
+    (1, 64, 128, 8, "MSE", 33),      # fused step at its limits: in_dim 64, 8 outputs (the deterministic head's maximum), one member
+    (2, 5, 128, 1, "MSE", 1),        # a single row
+    (2, 100, 128, 64, "MSPE", 40),   # 128 raw outputs (4 output tiles), wide input
+    (3, 23, 512, 11, "MSPE", 70),    # HalfCheetah-like dynamics (odd output width 22)
+    (2, 100, 128, 2, "MSE", 40),     # input too wide for the fused kernel: the general path on a deterministic head
 ]
 
 

@@ -143,6 +143,10 @@ def lib():
             raise CmbpoHipError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # torch first: its wheel bundles its own libamdhip64 / libhsa-runtime64, and the library must bind to THAT
+        # runtime (the one that owns the tensors it is handed).  Loaded the other way round the process ends up with
+        # two HIP runtimes and the second one finds no device.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)

@@ -100,17 +100,33 @@ __global__ __launch_bounds__(kThreads) void fakeenv_post_kernel(const PostArgs p
         sq = __fadd_rn(sq, __fmul_rn(dlt, dlt));
       }
     s_var[i] = sq / (float)E;
-    // average KL over all ordered pairs (i outer, j inner), pens/utils.py:49-56
+    // average KL over all ordered pairs (i outer, j inner), pens/utils.py:49-56.  Two exact savings: the a == c terms
+    // are 0.5 (v / (v + 1e-10) - 1) <= 0 (or NaN), which the clip turns into +0 -- adding +0 to the non-negative
+    // running sum changes nothing, so they are skipped; and (mu_c - mu_a)^2 == (mu_a - mu_c)^2 bit for bit, so the
+    // squared difference of a pair is computed once.
+    float dm2[kEMax][kEMax];
+#pragma unroll
+    for (int a = 0; a < kEMax; ++a)
+#pragma unroll
+      for (int c = a + 1; c < kEMax; ++c)
+        if (c < E) {
+          const float dm = __fsub_rn(mu[c], mu[a]);
+          dm2[a][c] = __fmul_rn(dm, dm);
+        }
+    float den[kEMax];
+#pragma unroll
+    for (int c = 0; c < kEMax; ++c)
+      if (c < E) den[c] = __fadd_rn(vr[c], 1e-10f);
     float acc = 0.0f;
 #pragma unroll
     for (int a = 0; a < kEMax; ++a) {
       if (a < E) {
 #pragma unroll
         for (int c = 0; c < kEMax; ++c) {
-          if (c < E) {
-            const float dm = __fsub_rn(mu[c], mu[a]);
-            const float num = __fadd_rn(__fmul_rn(dm, dm), vr[a]);
-            const float q = num / __fadd_rn(vr[c], 1e-10f);
+          if (c < E && c != a) {
+            const float d2 = (a < c) ? dm2[a][c] : dm2[c][a];
+            const float num = __fadd_rn(d2, vr[a]);
+            const float q = num / den[c];
             float pre = __fmul_rn(0.5f, __fsub_rn(q, 1.0f));
             pre = __fsub_rn(__fadd_rn(pre, ls[c]), ls[a]);
             pre = fminf(fmaxf(pre, 0.0f), 1e10f);

@@ -1,4 +1,4 @@
-"""CMBPO trainer loop -- host-side mirror of ``algorithms/cmbpo.py:30-600``.
+"""CMBPO trainer loop -- host-side mirror of ``algorithms/cmbpo.py:30-542``.
 
 The epoch structure is the reference's: Boltzmann-weighted start states from the archive -> imagined rollouts until the
 model batch is full -> real-environment sampling (as many steps as the model's current uncertainty asks for) ->

@@ -1,4 +1,4 @@
-"""CpoSampler -- host-side mirror of ``samplers/cpo_sampler.py:10-262``: one real-environment step per call, the
+"""CpoSampler -- host-side mirror of ``samplers/cpo_sampler.py:10-261``: one real-environment step per call, the
 policy's device kernels for the action / values, samples into the CPOBuffer.  The environment itself is serial host
 code (MuJoCo / safety-gym, out of scope); any object with gym's ``reset() / step(a) -> (obs, r, done,
 info)`` (``info['cost']`` optional) and ``action_space.shape`` works.
@@ -116,7 +116,7 @@ class CpoSampler:
             self._n_episodes += 1
 
     def log(self):
-        """cpo_sampler.py:238-262 (single process: mpi_sum is the identity)"""
+        """cpo_sampler.py:238-261 (single process: mpi_sum is the identity)"""
         logger = self.logger
         cost_rate = self.cum_cost / max(self._total_samples, 1)
         logger.log_tabular('RetEp', with_min_and_max=True)

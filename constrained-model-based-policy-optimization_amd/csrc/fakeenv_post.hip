@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kThreads) void fakeenv_post_kernel(const PostArgs p
         sq = __fadd_rn(sq, __fmul_rn(dlt, dlt));
       }
     s_var[i] = sq / (float)E;
-    // average KL over all ordered pairs (i outer, j inner), pens/utils.py:49-56.  Two exact savings: the a == c terms
+    // average KL over all ordered pairs (i outer, j inner), models/pens/utils.py:49-56.  Two exact savings: the a == c terms
     // are 0.5 (v / (v + 1e-10) - 1) <= 0 (or NaN), which the clip turns into +0 -- adding +0 to the non-negative
     // running sum changes nothing, so they are skipped; and (mu_c - mu_a)^2 == (mu_a - mu_c)^2 bit for bit, so the
     // squared difference of a pair is computed once.

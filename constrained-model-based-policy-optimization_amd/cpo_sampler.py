@@ -53,67 +53,73 @@ class CpoSampler:
     def batch_ready(self):
         return self.pool.size >= self.pool.max_size
 
-    def sample(self, timestep):
-        """cpo_sampler.py:125-190"""
-        if self._current_observation is None:
-            self._current_observation = np.squeeze(self.env.reset())
-            self._last_action = np.zeros(shape=self.env.action_space.shape)
-        outs = self.policy.get_action_outs(self._current_observation)
-        a, v_t, vc_t = outs['pi'], outs['v'], outs['vc']
-        logp_t, pi_info_t = outs['logp_pi'], outs['pi_info']
+    # -- one environment step --------------------------------------------------------------------------
+    def _begin_episode(self):
+        self._current_observation = np.squeeze(self.env.reset())
+        self._last_action = np.zeros(shape=self.env.action_space.shape)
 
-        next_observation, reward, terminal, info = self.env.step(a)
+    def _account(self, obs, act, nxt, rew, cost, done, info):
+        """Path statistics and the per-path record (cpo_sampler.py:151-176)."""
+        self.cum_cost += cost
+        self._path_cost += cost
+        self._path_return += rew
+        self._path_length += 1
+        self._total_samples += 1
+        rec = self._current_path
+        rec['observations'].append(obs)
+        rec['actions'].append(act)
+        rec['rewards'].append([rew])
+        rec['cost'].append([cost])
+        rec['terminals'].append([done])
+        rec['next_observations'].append(nxt)
+        rec['infos'].append(info)
+
+    def sample(self, timestep):
+        """One step of the real environment with the current policy (cpo_sampler.py:125-190): action, value and cost
+        value from the device kernels, transition into the pool, path bookkeeping, path end handling."""
+        if self._current_observation is None:
+            self._begin_episode()
+        obs = self._current_observation
+        pol = self.policy.get_action_outs(obs)
+        act = pol['pi']
+        nxt, rew, done, info = self.env.step(act)
         if self._render_mode:
             self.env.render(self._render_mode)
-        next_observation = np.squeeze(next_observation)
-        reward = np.squeeze(reward)
-        terminal = np.squeeze(terminal)
-        c = info.get('cost', 0)
-
-        self.pool.store(self._current_observation, a, next_observation, reward, v_t, c, vc_t, logp_t, pi_info_t,
-                        terminal, timestep)
-        self.logger.store(VVals=v_t, CostVVals=vc_t)
-        self.cum_cost += c
-        self._path_length += 1
-        self._path_return += reward
-        self._path_cost += c
-        self._total_samples += 1
-        for key, value in (('observations', self._current_observation), ('actions', a), ('rewards', [reward]),
-                           ('cost', [c]), ('terminals', [terminal]), ('next_observations', next_observation),
-                           ('infos', info)):
-            self._current_path[key].append(value)
-        self._current_observation = next_observation
-        self._last_action = a
-
-        if terminal or self._path_length >= self._max_path_length:
-            # an env time-out is not a true terminal state: the value target is bootstrapped; costs always are
-            if terminal and not (self._path_length >= self._max_path_length):
-                self.finish_all_paths(append_val=False, append_cval=True)
-            else:
-                self.finish_all_paths(append_val=True, append_cval=True)
-        return next_observation, reward, terminal, info
+        nxt, rew, done = np.squeeze(nxt), np.squeeze(rew), np.squeeze(done)
+        cost = info.get('cost', 0)
+        self.pool.store(obs, act, nxt, rew, pol['v'], cost, pol['vc'], pol['logp_pi'], pol['pi_info'], done, timestep)
+        self.logger.store(VVals=pol['v'], CostVVals=pol['vc'])
+        self._account(obs, act, nxt, rew, cost, done, info)
+        self._current_observation, self._last_action = nxt, act
+        timed_out = self._path_length >= self._max_path_length
+        if done or timed_out:
+            # a time-out is not a terminal state: the value target is bootstrapped then; the cost value always is
+            self.finish_all_paths(append_val=bool(timed_out or not done), append_cval=True)
+        return nxt, rew, done, info
 
     def finish_all_paths(self, append_val=False, append_cval=False, reset_path=True):
-        """cpo_sampler.py:192-236"""
-        if self._current_observation is None:
+        """Close the pool's open path with the right bootstrap values, optionally end the episode
+        (cpo_sampler.py:192-236)."""
+        obs = self._current_observation
+        if obs is None:
             return
-        last_val = self.policy.get_v(self._current_observation) if append_val else np.zeros((1,))
-        last_cval = self.policy.get_vc(self._current_observation) if append_cval else np.zeros((1,))
-        self.pool.finish_path(last_val, last_cval)
-        if reset_path:
-            self.logger.store(RetEp=self._path_return, EpLen=self._path_length, CostEp=self._path_cost,
-                              CostFullEp=self._path_cost / self._path_length * self._max_path_length)
-            self.last_path = {k: np.array(v) for k, v in self._current_path.items() if k != 'infos'}
-            self._max_path_return = max(self._max_path_return, self._path_return)
-            self._last_path_return = self._path_return
-            self.policy.reset()
-            self._current_observation = None
-            self._last_action = np.zeros(shape=self.env.action_space.shape)
-            self._path_length = 0
-            self._path_return = 0
-            self._path_cost = 0
-            self._current_path = defaultdict(list)
-            self._n_episodes += 1
+        zero = np.zeros((1,))
+        self.pool.finish_path(self.policy.get_v(obs) if append_val else zero,
+                              self.policy.get_vc(obs) if append_cval else zero)
+        if not reset_path:
+            return
+        n = self._path_length
+        self.logger.store(RetEp=self._path_return, EpLen=n, CostEp=self._path_cost,
+                          CostFullEp=self._path_cost / n * self._max_path_length)
+        self.last_path = {k: np.array(v) for k, v in self._current_path.items() if k != 'infos'}
+        self._last_path_return = self._path_return
+        self._max_path_return = max(self._max_path_return, self._path_return)
+        self._n_episodes += 1
+        self.policy.reset()
+        self._current_observation = None
+        self._last_action = np.zeros(shape=self.env.action_space.shape)
+        self._current_path = defaultdict(list)
+        self._path_length = self._path_return = self._path_cost = 0
 
     def log(self):
         """cpo_sampler.py:238-261 (single process: mpi_sum is the identity)"""

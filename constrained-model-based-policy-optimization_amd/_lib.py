@@ -105,6 +105,8 @@ SIGNATURES.update({
     "cmbpo_cg_step": (_i, [_i, _p, C.c_double, C.c_float, _p, _p, _p, _p, _p]),
     "cmbpo_pi_cg_solve": (_i, [_p, _bp, _p, C.c_double, C.c_float, _i, _p, _p, _p, _p, _p, _i, _p]),
     "cmbpo_pi_cg_release": (None, [_p]),
+    "cmbpo_pi_cg_iter": (_i, [_p, _bp, C.c_double, C.c_float, _p, _p, _p, _p, _p]),
+    "cmbpo_pi_cg_commit": (_i, [_p, _p]),
     "cmbpo_pi_cg_graph_launches": (C.c_long, []),
     "cmbpo_vec_lincomb": (_i, [_i, C.c_float, _p, C.c_float, _p, _p, _p]),
     "cmbpo_vec_dots": (_i, [_i, _i, C.POINTER(_p), C.POINTER(_p), _p, _p]),

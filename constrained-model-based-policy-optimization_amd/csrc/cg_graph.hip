@@ -36,8 +36,7 @@ long g_graph_launches = 0, g_graph_captures = 0;
 bool g_graph_ok = true;   // cleared when capture is not available; the eager loop is used from then on
 
 int iteration(cmbpo_pi_t *h, const CgKey &k) {
-  if (int rc = cmbpo_pi_fvp(h, &k.b, k.p, const_cast<float *>(k.vec), k.s)) return rc;
-  return cmbpo_cg_step(k.P, k.vec, k.inv_n, k.damping, k.x, k.r, k.p, k.scal, k.s);
+  return cmbpo_pi_cg_iter(h, &k.b, k.inv_n, k.damping, k.x, k.r, k.p, k.scal, k.s);
 }
 
 }  // namespace
@@ -53,7 +52,7 @@ extern "C" int cmbpo_pi_cg_solve(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, const
   k.inv_n = inv_n; k.damping = damping; k.iters = iters; k.P = cmbpo_pi_num_params(h); k.s = (hipStream_t)stream;
   if (int rc = cmbpo_cg_init(k.P, d_b, d_x, d_r, d_p, d_scal, stream)) return rc;
   if (int rc = iteration(h, k)) return rc;            // eager: also performs any one-time kernel attribute set-up
-  if (iters == 1) return CMBPO_OK;
+  if (iters == 1) return cmbpo_pi_cg_commit(d_scal, stream);
   if (use_graph && g_graph_ok) {
     const std::pair<const void *, const void *> gk(h, d_x);
     auto it = g_graphs.find(gk);
@@ -94,12 +93,12 @@ extern "C" int cmbpo_pi_cg_solve(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, const
     if (it != g_graphs.end()) {
       CMBPO_HIP_CHECK(hipGraphLaunch(it->second.exec, k.s));
       ++g_graph_launches;
-      return CMBPO_OK;
+      return cmbpo_pi_cg_commit(d_scal, stream);
     }
   }
   for (int i = 1; i < iters; ++i)
     if (int rc = iteration(h, k)) return rc;
-  return CMBPO_OK;
+  return cmbpo_pi_cg_commit(d_scal, stream);
 }
 
 // drop the cached graph of a handle (called before the handle is destroyed)

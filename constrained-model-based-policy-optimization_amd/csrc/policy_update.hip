@@ -391,6 +391,107 @@ __global__ __launch_bounds__(1024) void reduce_parts_kernel(const float *part, i
   }
 }
 
+// ---- one CG iteration's vector algebra on many workgroups (utilities/trust_region.py:37-44) ----------------------
+// k1: hv = sum of the Fisher-vector product's per-workgroup partials; z = hv / N + damping p; per-workgroup p.z
+// k2: alpha = rr / (p.z + EPS); x += alpha p; r -= alpha z; per-workgroup r.r
+// k3: rr_new = r.r; p = r + (rr_new / rr) p
+// Dot products are float64 sums of per-workgroup partials that EVERY workgroup adds up in the same order (no atomics,
+// reproducible).  scal[0] = r.r of the current residual; k3 parks the new value in scal[1] and the next k1 (or the
+// final commit) moves it, so no workgroup reads scal[0] while another one updates it.
+__device__ __forceinline__ double ordered_sum(const double *part, int n, double *sm) {
+  // every workgroup: the same strided partial sums, the same tree
+  double s = 0.0;
+  for (int w = threadIdx.x; w < n; w += blockDim.x) s += part[w];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[wv] = s;
+  __syncthreads();
+  double t = 0.0;
+  for (int k = 0; k < nw; ++k) t += sm[k];
+  return t;
+}
+
+__global__ __launch_bounds__(1024) void cg_k1_kernel(const float *part, int part_ld, int n_parts, int P, float inv_n,
+                                                     float damping, const float *p, float *z, double *pzp, double *scal) {
+  __shared__ float sm[16][64];
+  __shared__ double smd[64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + c;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && scal[1] >= 0.0) {
+    scal[0] = scal[1];
+    scal[1] = -1.0;
+  }
+  float s = 0.0f;
+  if (i < P)
+    for (int w = g; w < n_parts; w += 16) s += part[(size_t)w * part_ld + i];
+  sm[g][c] = s;
+  __syncthreads();
+  double pz = 0.0;
+  if (g == 0) {
+    if (i < P) {
+      float t[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t[k] = sm[k][c];
+#pragma unroll
+      for (int st = 1; st < 16; st <<= 1)
+#pragma unroll
+        for (int k = 0; k + st < 16; k += 2 * st) t[k] += t[k + st];
+      const float pi = p[i];
+      const float zi = t[0] * inv_n + damping * pi;
+      z[i] = zi;
+      pz = (double)pi * (double)zi;
+    }
+    smd[c] = pz;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < 64; ++k) t += smd[k];
+    pzp[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void cg_k2_kernel(int P, int n1, const double *pzp, const float *p, const float *z,
+                                                    float *x, float *r, double *rrp, const double *scal) {
+  __shared__ double sm[4];
+  const double pz = ordered_sum(pzp, n1, sm);
+  const float rr_old = (float)scal[0];
+  const float alpha = rr_old / ((float)pz + 1e-8f);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double rr = 0.0;
+  if (i < P) {
+    x[i] += alpha * p[i];
+    const float ri = r[i] - alpha * z[i];
+    r[i] = ri;
+    rr = (double)ri * (double)ri;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) rr += __shfl_down(rr, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = rr;
+  __syncthreads();
+  if (threadIdx.x == 0) rrp[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+__global__ __launch_bounds__(256) void cg_k3_kernel(int P, int n2, const double *rrp, const float *r, float *p, double *scal) {
+  __shared__ double sm[4];
+  const double rr = ordered_sum(rrp, n2, sm);
+  const float rr_new = (float)rr, rr_old = (float)scal[0];
+  const float beta = rr_new / rr_old;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < P) p[i] = r[i] + beta * p[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) scal[1] = (double)rr_new;
+}
+
+__global__ void cg_commit_kernel(double *scal) {
+  if (scal[1] >= 0.0) {
+    scal[0] = scal[1];
+    scal[1] = -1.0;
+  }
+}
+
 }  // namespace
 
 struct cmbpo_pi {
@@ -398,6 +499,9 @@ struct cmbpo_pi {
   float *blob;       // parameters pack | direction pack
   float *parts;      // [2 n_cu][part_ld] per-workgroup partial gradients
   int part_ld;
+  int last_grid;     // workgroups (= partial vectors) of the last gradient / FVP launch
+  float *cg_z;       // [part_ld] z of the current CG iteration
+  double *cg_part;   // [P / 64 + P / 256 + 2] per-workgroup partial dot products
   size_t pack_floats;
   size_t off_F0, off_F1, off_F2, off_B1, off_B2, off_b0, off_b1, off_b2, off_ls;
   int n_cu;
@@ -462,7 +566,8 @@ int launch_pi_n(cmbpo_pi *h, PiArgs &a, hipStream_t s) {
   const int grid = tiles < resident ? tiles : resident;
   a.part = h->parts; a.part_ld = h->part_ld;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, s, a);
-  if (MODE != MODE_EVAL)
+  h->last_grid = grid;
+  if (MODE != MODE_EVAL && a.vec != nullptr)
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(cmbpo_ceil_div(h->d.P, 64)), dim3(1024), 0, s, h->parts, h->part_ld, grid,
                        h->d.P, a.vec);
   CMBPO_HIP_CHECK(hipGetLastError());
@@ -524,7 +629,9 @@ extern "C" int cmbpo_pi_create(cmbpo_pi_t **out, int obs_dim, int hidden, int ac
   h->part_ld = (d.P + 63) / 64 * 64;
   h->parts = nullptr;
   if (hipMalloc(reinterpret_cast<void **>(&h->blob), 2 * off * sizeof(float)) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void **>(&h->parts), (size_t)2 * h->n_cu * h->part_ld * sizeof(float)) != hipSuccess) {
+      hipMalloc(reinterpret_cast<void **>(&h->parts), (size_t)2 * h->n_cu * h->part_ld * sizeof(float)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&h->cg_z), (size_t)h->part_ld * sizeof(float)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&h->cg_part), (size_t)(h->part_ld / 64 + h->part_ld / 256 + 4) * sizeof(double)) != hipSuccess) {
     cmbpo_set_error("cmbpo_pi_create: hipMalloc failed");
     if (h->blob) (void)hipFree(h->blob);
     delete h;
@@ -538,6 +645,8 @@ extern "C" void cmbpo_pi_destroy(cmbpo_pi_t *h) {
   if (!h) return;
   if (h->blob) (void)hipFree(h->blob);
   if (h->parts) (void)hipFree(h->parts);
+  if (h->cg_z) (void)hipFree(h->cg_z);
+  if (h->cg_part) (void)hipFree(h->cg_part);
   delete h;
 }
 
@@ -570,6 +679,35 @@ extern "C" int cmbpo_pi_fvp(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, const floa
   if (int rc = do_pack(h, h->blob + h->pack_floats, d_v, s)) return rc;
   a.vec = d_vec; a.sums = nullptr;
   return launch_pi<MODE_FVP>(h, a, s);
+}
+
+// One CG iteration on the handle's own partial vectors (single-GPU path of cmbpo_pi_cg_solve): Fisher-vector product of
+// direction d_p, then the three vector kernels; d_scal[0] carries r.r (see cg_k1_kernel), d_scal[1] must be < 0 on entry
+// to the first iteration (cmbpo_cg_init leaves it there) and cmbpo_pi_cg_commit finishes the hand-over after the last.
+extern "C" int cmbpo_pi_cg_iter(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, double inv_n, float damping, float *d_x,
+                                float *d_r, float *d_p, double *d_scal, void *stream) {
+  PiArgs a{};
+  if (int rc = fill_args(h, b, a, "cmbpo_pi_cg_iter")) return rc;
+  CMBPO_REQUIRE(b->logstd_old && d_x && d_r && d_p && d_scal, "cmbpo_pi_cg_iter: NULL buffer");
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = do_pack(h, h->blob + h->pack_floats, d_p, s)) return rc;
+  a.vec = nullptr; a.sums = nullptr;              // partial vectors only: cg_k1 adds them up
+  if (int rc = launch_pi<MODE_FVP>(h, a, s)) return rc;
+  const int P = h->d.P, n1 = cmbpo_ceil_div(P, 64), n2 = cmbpo_ceil_div(P, 256);
+  double *pzp = h->cg_part, *rrp = h->cg_part + n1;
+  hipLaunchKernelGGL(cg_k1_kernel, dim3(n1), dim3(1024), 0, s, h->parts, h->part_ld, h->last_grid, P, (float)inv_n, damping,
+                     d_p, h->cg_z, pzp, d_scal);
+  hipLaunchKernelGGL(cg_k2_kernel, dim3(n2), dim3(256), 0, s, P, n1, pzp, d_p, h->cg_z, d_x, d_r, rrp, d_scal);
+  hipLaunchKernelGGL(cg_k3_kernel, dim3(n2), dim3(256), 0, s, P, n2, rrp, d_r, d_p, d_scal);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_pi_cg_commit(double *d_scal, void *stream) {
+  CMBPO_REQUIRE(d_scal != nullptr, "cmbpo_pi_cg_commit: NULL scalars");
+  hipLaunchKernelGGL(cg_commit_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_scal);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
 }
 
 extern "C" int cmbpo_pi_eval(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, double *d_sums, void *stream) {

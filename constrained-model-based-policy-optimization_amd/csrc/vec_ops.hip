@@ -41,7 +41,10 @@ __global__ __launch_bounds__(kT) void cg_init_kernel(int P, const float *b, floa
     rr += (double)bi * (double)bi;
   }
   rr = block_sum_all(rr, sm);
-  if (threadIdx.x == 0) scal[0] = (double)(float)rr;   // r_dot_old, a float32 value in the reference
+  if (threadIdx.x == 0) {
+    scal[0] = (double)(float)rr;   // r_dot_old, a float32 value in the reference
+    scal[1] = -1.0;                // no pending hand-over (cmbpo_pi_cg_iter)
+  }
 }
 
 // z = hp_sum * inv_n + damping * p ; alpha = rr / (p.z + EPS) ; x += alpha p ; r -= alpha z ;

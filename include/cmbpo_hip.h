@@ -338,6 +338,12 @@ int cmbpo_pi_cg_solve(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, const float *d_b
                       int iters, float *d_x, float *d_r, float *d_p, float *d_vec, double *d_scal,
                       int use_graph, void *stream);
 void cmbpo_pi_cg_release(cmbpo_pi_t *h);
+/* The iteration cmbpo_pi_cg_solve repeats: Fisher-vector product of direction d_p (kept as per-workgroup partial
+ * vectors), z = Hp / N + damping p, alpha, x, r, beta, p updated by three multi-workgroup kernels with ordered float64
+ * dot products.  d_scal[0] = r.r; d_scal[1] < 0 on entry to the first iteration; cmbpo_pi_cg_commit after the last. */
+int cmbpo_pi_cg_iter(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, double inv_n, float damping, float *d_x,
+                     float *d_r, float *d_p, double *d_scal, void *stream);
+int cmbpo_pi_cg_commit(double *d_scal, void *stream);
 long cmbpo_pi_cg_graph_launches(void);   /* graph replays so far; -1: stream capture unavailable, eager loop in use */
 /* d_out = a * d_x + b * d_y (d_y may be NULL): Hx = hvp / N + damping v, the step x = (v + nu w) / (lam + eps)
  * (policies/cpo_policy.py:266) and the trial parameters old - step * x (:278). */

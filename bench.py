@@ -306,7 +306,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{task} imagined rollout: E=7 x (37->512->512->60) swish ensemble, 5 elites, "
+            "config": {"workload": f"{task} imagined rollout: E={E} x ({D + A}->{H}->{H}->{2 * (D + 1)}) swish ensemble, 5 elites, "
                                    f"3+3 critics 128x128, tanh policy 128x128, B={B} branches/GPU, maxroll 35 "
                                    f"(34 steps), reset->sample*->finish_all_paths->get()",
                        "branches_per_gpu": B, "horizon": MAXROLL - 1, "task": task,

@@ -349,6 +349,7 @@ def main():
     gen_update_pi(HERE)
     gen_cpobuffer(HERE)
     gen_pe_train(HERE)
+    gen_loop_helpers(HERE)
     print("golden vectors written to", HERE)
 
 
@@ -597,8 +598,53 @@ def gen_pe_train(out):
     np.savez_compressed(os.path.join(out, "g9_pe_train.npz"), **cases)
 
 
+
+# ------------------------------------------------------------------------------------------------
+# G10: small pure functions of the trainer loop
+# ------------------------------------------------------------------------------------------------
+def gen_loop_helpers(out):
+    """format_samples_for_dyn (models/pens/pe_factory.py:74-107), update_dict (models/pens/logger.py:7-17) and the
+    rollout-length schedule of CMBPO._set_rollout_length (algorithms/cmbpo.py:493-509), run from the reference."""
+    from models.pens.pe_factory import format_samples_for_dyn
+    from models.pens.logger import update_dict
+    from algorithms.cmbpo import CMBPO
+    rng = np.random.default_rng(77)
+    n, D, A = 50, 6, 2
+    samples = dict(observations=rng.standard_normal((n, D)).astype(np.float32),
+                   actions=rng.standard_normal((n, A)).astype(np.float32),
+                   next_observations=rng.standard_normal((n, D)).astype(np.float32),
+                   rewards=rng.standard_normal((n, 1)).astype(np.float32),
+                   costs=(rng.random((n,)) < 0.3).astype(np.float32),
+                   terminals=np.zeros((n, 1), np.float32))
+    data = {"s_" + k: v for k, v in samples.items()}
+    for tag, kw in (("r", dict(append_r=True, append_c=False)), ("rc", dict(append_r=True, append_c=True)),
+                    ("none", dict(append_r=False, append_c=False))):
+        x, y = format_samples_for_dyn(samples, **kw)
+        data["dyn_in_" + tag], data["dyn_out_" + tag] = x, y
+    a = {"k1": 1.0, "k2": 4.0, "only_a": 7.0}
+    b = {"k1": 3.0, "k2": -2.0, "only_b": 5.0}
+    for i, (wa, wb) in enumerate(((0.5, 0.5), (0.25, 0.75), (1.0, 1.0))):
+        d = update_dict(a, b, weight_a=wa, weight_b=wb)
+        data[f"ud{i}_keys"] = np.array(sorted(d))
+        data[f"ud{i}_vals"] = np.array([d[k] for k in sorted(d)])
+        data[f"ud{i}_w"] = np.array([wa, wb])
+    sched = []
+    for schedule in ([10, 500, 5, 30], [20, 100, 1, 15], [0, 1, 4, 4]):
+        for epoch in (0, 5, 10, 11, 60, 255, 500, 900):
+            fake = types.SimpleNamespace(_rollout_schedule=schedule, _epoch=epoch,
+                                         model_sampler=types.SimpleNamespace(set_max_path_length=lambda v: None))
+            CMBPO._set_rollout_length(fake)
+            sched.append(schedule + [epoch, fake._rollout_length])
+    data["schedule"] = np.array(sched)
+    np.savez_compressed(os.path.join(out, "g10_loop_helpers.npz"), **data)
+    print("loop helpers:", len(sched), "schedule points")
+
+
 if __name__ == "__main__":
-    if "--pe-train-only" in sys.argv:
+    if "--loop-helpers-only" in sys.argv:
+        install_stubs()
+        gen_loop_helpers(HERE)
+    elif "--pe-train-only" in sys.argv:
         install_stubs()
         gen_pe_train(HERE)
     elif "--cpobuffer-only" in sys.argv:

@@ -350,6 +350,7 @@ def main():
     gen_cpobuffer(HERE)
     gen_pe_train(HERE)
     gen_loop_helpers(HERE)
+    gen_cpobuffer_archive(HERE)
     print("golden vectors written to", HERE)
 
 
@@ -640,8 +641,62 @@ def gen_loop_helpers(out):
     print("loop helpers:", len(sched), "schedule points")
 
 
+
+# ------------------------------------------------------------------------------------------------
+# G11: CPOBuffer archive accessors over several epochs (start-state sampling of the trainer loop)
+# ------------------------------------------------------------------------------------------------
+def gen_cpobuffer_archive(out):
+    """buffers/cpobuffer.py:292-530 after three epochs have been moved to the archive: boltz_dist,
+    distributed_batch_from_archive, epoch_batch, rand_batch_from_archive, get_archive under np.random.seed."""
+    from buffers.cpobuffer import CPOBuffer
+    rng = np.random.default_rng(909)
+    D, A = 5, 2
+    buf = CPOBuffer(size=40, archive_size=100, observation_space=_Space(D), action_space=_Space(A))
+    buf.initialize({"mu": [A], "log_std": [A]}, gamma=0.99, lam=0.95, cost_gamma=0.97, cost_lam=0.5)
+    plan = [(3, [5, 9]), (4, [12]), (6, [3, 3, 10])]          # (epoch tag, path lengths)
+    n = sum(sum(ls) for _, ls in plan)
+    data = dict(D=D, A=A, obs=rng.standard_normal((n, D)).astype(np.float32), act=rng.standard_normal((n, A)).astype(np.float32),
+                rew=rng.standard_normal(n).astype(np.float32), val=rng.standard_normal(n).astype(np.float32),
+                cost=(rng.random(n) < 0.3).astype(np.float32), cval=rng.standard_normal(n).astype(np.float32),
+                logp=rng.standard_normal(n).astype(np.float32), mu=rng.standard_normal((n, A)).astype(np.float32),
+                log_std=np.full((n, A), -0.5, np.float32), last=rng.standard_normal((8, 2)).astype(np.float32),
+                plan_epochs=np.array([e for e, _ in plan]), plan_lengths=np.array([len(ls) for _, ls in plan]),
+                path_lengths=np.array([l for _, ls in plan for l in ls]))
+    i = p = 0
+    for epoch, ls in plan:
+        for L in ls:
+            for _ in range(L):
+                buf.store(data["obs"][i], data["act"][i], data["obs"][i] + 1, data["rew"][i], data["val"][i], data["cost"][i],
+                          data["cval"][i], data["logp"][i], {"mu": data["mu"][i], "log_std": data["log_std"][i]}, False, epoch)
+                i += 1
+            buf.finish_path(data["last"][p, 0:1], data["last"][p, 1:2])
+            p += 1
+        buf.get()
+    data["arch_size"], data["epochs_list"] = buf.arch_size, np.array(buf.epochs_list)
+    data["max_ep"], data["min_ep"] = buf.max_ep, buf.min_ep
+    kls = np.array([0.02, 0.5, 0.1])
+    data["kls"] = kls
+    dist = buf.boltz_dist(kls, alpha=2)
+    data["boltz"] = dist
+    np.random.seed(5)
+    b = buf.distributed_batch_from_archive(23, dist, fields=["observations", "pi_infos"])
+    data["dist_obs"], data["dist_mu"] = b["observations"], b["mu"]
+    e = buf.epoch_batch(7, buf.epochs_list, fields=["observations", "pi_infos"])
+    data["ep_obs"], data["ep_ls"] = e["observations"], e["log_std"]
+    r = buf.rand_batch_from_archive(11, fields=["observations", "rewards"])
+    data["rand_obs"], data["rand_rew"] = r["observations"], r["rewards"]
+    arch = buf.get_archive(["observations", "actions", "next_observations", "rewards", "costs", "terminals", "epochs"])
+    for k, v in arch.items():
+        data["arch_" + k] = v
+    np.savez_compressed(os.path.join(out, "g11_cpobuffer_archive.npz"), **data)
+    print("cpobuffer archive:", buf.arch_size, "samples, epochs", list(buf.epochs_list))
+
+
 if __name__ == "__main__":
-    if "--loop-helpers-only" in sys.argv:
+    if "--archive-only" in sys.argv:
+        install_stubs()
+        gen_cpobuffer_archive(HERE)
+    elif "--loop-helpers-only" in sys.argv:
         install_stubs()
         gen_loop_helpers(HERE)
     elif "--pe-train-only" in sys.argv:

@@ -56,3 +56,48 @@ def test_cpobuffer_matches_reference(hip_lib):
     assert batch["observations"].shape == (16, D) and batch["log_std"].shape == (16, A)
     ep = buf.epoch_batch(8, buf.epochs_list, fields=["observations", "pi_infos"])
     assert ep["observations"].shape == (1, 8, D)
+
+
+def test_archive_accessors_match_reference_over_epochs(hip_lib):
+    """Golden G11: three epochs moved to the archive, then the start-state sampling accessors of the trainer loop
+    (buffers/cpobuffer.py:292-530) under the same np.random seed -- identical draws, identical batches."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cmbpo_amd.cpobuffer import CPOBuffer
+    g = np.load(os.path.join(GOLD, "g11_cpobuffer_archive.npz"))
+    D, A = int(g["D"]), int(g["A"])
+
+    class _S:
+        def __init__(self, d):
+            self.shape = (d,)
+
+    buf = CPOBuffer(40, 100, _S(D), _S(A))
+    buf.initialize({"mu": [A], "log_std": [A]}, gamma=0.99, lam=0.95, cost_gamma=0.97, cost_lam=0.5)
+    i = p = 0
+    lengths = iter(g["path_lengths"])
+    for epoch, n_paths in zip(g["plan_epochs"], g["plan_lengths"]):
+        for _ in range(int(n_paths)):
+            for _ in range(int(next(lengths))):
+                buf.store(g["obs"][i], g["act"][i], g["obs"][i] + 1, g["rew"][i], g["val"][i], g["cost"][i], g["cval"][i],
+                          g["logp"][i], {"mu": g["mu"][i], "log_std": g["log_std"][i]}, False, int(epoch))
+                i += 1
+            buf.finish_path(g["last"][p, 0:1], g["last"][p, 1:2])
+            p += 1
+        buf.get()
+    assert buf.arch_size == int(g["arch_size"]) and list(buf.epochs_list) == list(g["epochs_list"])
+    assert buf.max_ep == int(g["max_ep"]) and buf.min_ep == int(g["min_ep"])
+    dist = buf.boltz_dist(g["kls"], alpha=2)
+    np.testing.assert_array_equal(dist, g["boltz"])
+    np.random.seed(5)
+    b = buf.distributed_batch_from_archive(23, dist, fields=["observations", "pi_infos"])
+    np.testing.assert_array_equal(b["observations"], g["dist_obs"])
+    np.testing.assert_array_equal(b["mu"], g["dist_mu"])
+    e = buf.epoch_batch(7, buf.epochs_list, fields=["observations", "pi_infos"])
+    np.testing.assert_array_equal(e["observations"], g["ep_obs"])
+    np.testing.assert_array_equal(e["log_std"], g["ep_ls"])
+    r = buf.rand_batch_from_archive(11, fields=["observations", "rewards"])
+    np.testing.assert_array_equal(r["observations"], g["rand_obs"])
+    np.testing.assert_array_equal(r["rewards"], g["rand_rew"])
+    arch = buf.get_archive(["observations", "actions", "next_observations", "rewards", "costs", "terminals", "epochs"])
+    for k, v in arch.items():
+        np.testing.assert_array_equal(v, g["arch_" + k], err_msg=k)

@@ -19,6 +19,7 @@ Event order, bootstraps and the budget rule follow ``model_sampler.py:239-375`` 
 ``sample()`` returns ``(next_obs, reward, terminal, info)`` like the reference, but as slot-indexed CUDA
 tensors (the trainer only reads ``info['alive_ratio']``, ``algorithms/cmbpo.py:254-263``).
 """
+import ctypes as C
 from collections import OrderedDict
 
 import numpy as np
@@ -185,34 +186,43 @@ class ModelSampler:
                 inds_t = self._elites[draw]
             else:
                 inds_t = self._scatter(model_inds, idx[:n], None, torch.int32)
-            # policy: pi, logp, mu, log_std at the current observations
-            pol.actor.forward_device(t["cur_obs"], eps_t,
-                                     dict(pi=t["act_t"], logp_pi=t["logp_t"], mu=t["mu_t"], log_std=t["ls_t"]),
-                                     row_idx=idx, n_rows=n)
-            # dynamics ensemble + FakeEnv post-processing
             if getattr(self, "_scratch", None) is None or self._scratch[0].shape[1] != B:
                 E, O = env._model.num_nets, env.output_dim
                 self._scratch = (torch.empty((E, B, O), dtype=torch.float32, device=self.device),
                                  torch.empty((E, B, O), dtype=torch.float32, device=self.device))
-            env.step_device(t["cur_obs"], t["act_t"], inds_t,
-                            dict(next_obs=t["next_obs"], rew=t["rew_t"], term=t["term_t"], cost=t["cost_t"],
-                                 dkl_path=t["dkl_t"], ep_var_mean=t["epv_t"]),
-                            row_idx=idx, n_rows=n, scratch=self._scratch)
             rs.max_samples = int(max_samples) if max_samples else 0
             rs.dkl_lim = float(self.dkl_lim)
             rs.max_path_length = self._max_path_length
             rs.use_host_budget = 0
-            if self.comm is not None and self.comm.world > 1 and rs.max_samples > 0:
-                # budget rule across shards: gather {n_alive, n_unc, total}, rank the survivors globally
-                pool._call("cmbpo_rollout_count")
-                rows = self.comm.all_gather_i32(t["iscal"][8:12]).cpu().numpy()
-                excess, rank_off = budget_plan(rows, self.comm.rank, rs.max_samples)
-                rs.use_host_budget, rs.host_excess, rs.host_rank_off = 1, int(excess), int(rank_off)
-            pool._call("cmbpo_rollout_decide")
-            pool._call("cmbpo_rollout_finish", 0)
-            pool._call("cmbpo_rollout_store")
-            self._critics("next_obs", "v_n", "vc_n", n)
-            pool._call("cmbpo_rollout_finish", 1)
+            exchange = sharded and rs.max_samples > 0
+            if not exchange and env.kernel_events is None:
+                # the whole step in one call: at small rollout batches a step is bound by host latency
+                _lib.check(_lib.lib().cmbpo_rollout_step(
+                    C.byref(rs), n, pol.actor.mlp.handle, env._model.mlp.handle, pol.v.mlp.handle, pol.vc.mlp.handle,
+                    env._task_id, env._model.num_nets, eps_t.data_ptr(), inds_t.data_ptr(),
+                    self._scratch[0].data_ptr(), self._scratch[1].data_ptr(), _lib.current_stream()),
+                    "cmbpo_rollout_step")
+            else:
+                # policy: pi, logp, mu, log_std at the current observations
+                pol.actor.forward_device(t["cur_obs"], eps_t,
+                                         dict(pi=t["act_t"], logp_pi=t["logp_t"], mu=t["mu_t"], log_std=t["ls_t"]),
+                                         row_idx=idx, n_rows=n)
+                # dynamics ensemble + FakeEnv post-processing
+                env.step_device(t["cur_obs"], t["act_t"], inds_t,
+                                dict(next_obs=t["next_obs"], rew=t["rew_t"], term=t["term_t"], cost=t["cost_t"],
+                                     dkl_path=t["dkl_t"], ep_var_mean=t["epv_t"]),
+                                row_idx=idx, n_rows=n, scratch=self._scratch)
+                if exchange:
+                    # budget rule across shards: gather {n_alive, n_unc, total}, rank the survivors globally
+                    pool._call("cmbpo_rollout_count")
+                    rows = self.comm.all_gather_i32(t["iscal"][8:12]).cpu().numpy()
+                    excess, rank_off = budget_plan(rows, self.comm.rank, rs.max_samples)
+                    rs.use_host_budget, rs.host_excess, rs.host_rank_off = 1, int(excess), int(rank_off)
+                pool._call("cmbpo_rollout_decide")
+                pool._call("cmbpo_rollout_finish", 0)
+                pool._call("cmbpo_rollout_store")
+                self._critics("next_obs", "v_n", "vc_n", n)
+                pool._call("cmbpo_rollout_finish", 1)
             # the host sync of the step: counters of what finished / was stored + the accumulators
             isc, dsc = self._read_scalars()
             if int(isc[_lib.I_N_FIN_PRE]) + int(isc[_lib.I_N_FIN_POST]) > 0:

@@ -239,6 +239,13 @@ int cmbpo_rollout_store(const cmbpo_rollout_t *r, void *stream);
 /* Rebuild the ordered alive list from `alive` (replaces the boolean-mask
  * compaction of model_sampler.py:300-311,361-372). */
 int cmbpo_rollout_compact(const cmbpo_rollout_t *r, void *stream);
+/* The whole step in one call (single-GPU jobs without a cross-shard budget exchange): cmbpo_policy_forward ->
+ * cmbpo_ens_forward -> cmbpo_fakeenv_post -> decide -> finish(PRE) -> store -> cmbpo_ens_predict_mean x 2 at next_obs ->
+ * finish(POST), every buffer taken from *r (slot-indexed d_eps [B, act], d_elite [B]; scratch d_mean / d_var
+ * [E, B, obs + 1]).  n_alive = the host's copy of iscal[CMBPO_I_N_ALIVE]. */
+int cmbpo_rollout_step(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy, cmbpo_mlp_t *model,
+                       cmbpo_mlp_t *v, cmbpo_mlp_t *vc, int task, int ensemble, const float *d_eps,
+                       const int32_t *d_elite, float *d_mean, float *d_var, void *stream);
 
 /* ModelBuffer.get (modelbuffer.py:184-226): d_offsets[B+1] = exclusive scan of
  * len; d_stats[8] = {n, adv_mean, adv_std, cadv_mean, ret_mean, cret_mean}

@@ -118,7 +118,8 @@ __device__ __forceinline__ bool too_uncertain(const cmbpo_rollout_t &r, int b) {
   return r.uncertainty_mode && (r.dkl_acc[b] + (double)r.dkl_t[b] >= r.dkl_lim);
 }
 
-// pass 1 (grid): uncertainty flags -> fin_code, counts of this step
+// pass 1 (grid): uncertainty flags -> fin_code; per-workgroup {count, sum of dkl_t} into the scratch array (no counter
+// to clear beforehand, no atomics: pass 2 adds the partials in workgroup order)
 __global__ __launch_bounds__(256) void decide_flags_kernel(const cmbpo_rollout_t r) {
   __shared__ double sm_d[16];
   const int n = r.iscal[CMBPO_I_N_ALIVE];
@@ -134,26 +135,37 @@ __global__ __launch_bounds__(256) void decide_flags_kernel(const cmbpo_rollout_t
   const double c = block_sum((double)cnt, sm_d);
   const double d = block_sum(dsum, sm_d);
   if (threadIdx.x == 0) {
-    if (c > 0.0) atomicAdd(&r.iscal[CMBPO_I_N_UNC], (int)c);
-    atomicAdd(&r.dscal[CMBPO_D_DKL_SUM_T], d);
+    r.store_part[2 * blockIdx.x] = c;
+    r.store_part[2 * blockIdx.x + 1] = d;
   }
 }
 
-__global__ void decide_clear_kernel(const cmbpo_rollout_t r) {
-  r.iscal[CMBPO_I_N_UNC] = 0;
-  r.iscal[CMBPO_I_N_STORED] = 0;
-  r.iscal[CMBPO_I_N_FIN_POST] = 0;
-  r.dscal[CMBPO_D_DKL_SUM_T] = 0.0;
-}
-
-// pass 2 (one workgroup): budget rule -- the first `excess` surviving rows in index order are finished too.
-// Exits at once when the budget is not exceeded (every step but the last one or two of a rollout).
-__global__ __launch_bounds__(kScanThreads) void decide_budget_kernel(const cmbpo_rollout_t r, int count_only) {
+// pass 2 (one workgroup): this step's counters, then the budget rule -- the first `excess` surviving rows in index
+// order are finished too.  Exits at once when the budget is not exceeded (every step but the last one or two).
+__global__ __launch_bounds__(kScanThreads) void decide_budget_kernel(const cmbpo_rollout_t r, int count_only, int n_parts) {
   __shared__ int sm_i[17];
   __shared__ double sm_d[16];
+  __shared__ int s_unc;
   const int tid = threadIdx.x;
   const int n = r.iscal[CMBPO_I_N_ALIVE];
-  const int n_unc = r.iscal[CMBPO_I_N_UNC];
+  {
+    double c = 0.0, d = 0.0;
+    for (int w = tid; w < n_parts; w += kScanThreads) {
+      c += r.store_part[2 * w];
+      d += r.store_part[2 * w + 1];
+    }
+    c = block_sum(c, sm_d);
+    d = block_sum(d, sm_d);
+    if (tid == 0) {
+      s_unc = (int)c;
+      r.iscal[CMBPO_I_N_UNC] = (int)c;
+      r.dscal[CMBPO_D_DKL_SUM_T] = d;
+      r.iscal[CMBPO_I_N_STORED] = 0;
+      r.iscal[CMBPO_I_N_FIN_POST] = 0;
+    }
+    __syncthreads();
+  }
+  const int n_unc = s_unc;
   if (tid == 0) {
     // the row other shards gather: {n_alive, n_unc, total_samples, 0}
     r.iscal[8] = n;
@@ -562,24 +574,23 @@ extern "C" int cmbpo_rollout_reset(const cmbpo_rollout_t *r, void *stream) {
 }
 
 static int launch_decide(const cmbpo_rollout_t *r, int count_only, hipStream_t s) {
-  hipLaunchKernelGGL(decide_clear_kernel, dim3(1), dim3(1), 0, s, *r);
   const int blocks = cmbpo_ceil_div(r->B, 256) < 512 ? cmbpo_ceil_div(r->B, 256) : 512;
   hipLaunchKernelGGL(decide_flags_kernel, dim3(blocks), dim3(256), 0, s, *r);
-  hipLaunchKernelGGL(decide_budget_kernel, dim3(1), dim3(kScanThreads), 0, s, *r, count_only);
+  hipLaunchKernelGGL(decide_budget_kernel, dim3(1), dim3(kScanThreads), 0, s, *r, count_only, blocks);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }
 
 extern "C" int cmbpo_rollout_decide(const cmbpo_rollout_t *r, void *stream) {
   if (int rc = check_rollout(r, "cmbpo_rollout_decide")) return rc;
-  CMBPO_REQUIRE(r->dkl_t && r->dkl_acc, "cmbpo_rollout_decide: NULL dkl arrays");
+  CMBPO_REQUIRE(r->dkl_t && r->dkl_acc && r->store_part, "cmbpo_rollout_decide: NULL dkl arrays / scratch");
   CMBPO_REQUIRE(r->world >= 1 && r->rank >= 0 && r->rank < r->world, "cmbpo_rollout_decide: bad rank/world");
   return launch_decide(r, 0, (hipStream_t)stream);
 }
 
 extern "C" int cmbpo_rollout_count(const cmbpo_rollout_t *r, void *stream) {
   if (int rc = check_rollout(r, "cmbpo_rollout_count")) return rc;
-  CMBPO_REQUIRE(r->dkl_t && r->dkl_acc, "cmbpo_rollout_count: NULL dkl arrays");
+  CMBPO_REQUIRE(r->dkl_t && r->dkl_acc && r->store_part, "cmbpo_rollout_count: NULL dkl arrays / scratch");
   return launch_decide(r, 1, (hipStream_t)stream);
 }
 

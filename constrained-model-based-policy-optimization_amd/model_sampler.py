@@ -150,6 +150,7 @@ class ModelSampler:
         self._host = dict(total_samples=0.0, total_dkl=0.0)
         elites = np.asarray(self.env._model.elite_inds, dtype=np.int32)
         self._elites = torch.as_tensor(elites, device=self.device)
+        self._draws = None
 
     def _scatter(self, compact, idx, width=None, dtype=torch.float32):
         """Test hook: a draw given in the reference's compact (alive-only) order -> slot order."""
@@ -177,13 +178,23 @@ class ModelSampler:
         n, B, A = pool.n_alive, self.batch_size, pool.act_dim
         with torch.cuda.device(self.device):
             idx = t["alive_idx"]
+            if eps is None or model_inds is None:
+                # action noise and elite picks are drawn for several steps at a time (three torch launches per chunk
+                # instead of per step: at small rollout batches a step is a chain of launch latencies)
+                ck = getattr(self, "_draws", None)
+                if ck is None or ck[0] >= ck[1].shape[0] or ck[1].shape[1] != B:
+                    K = max(1, min(8, int(2 ** 28 // max(B * A * 4, 1))))
+                    e_ck = torch.randn((K, B, A), generator=self._gen, dtype=torch.float32, device=self.device)
+                    d_ck = torch.randint(0, len(self._elites), (K, B), generator=self._gen, device=self.device)
+                    ck = self._draws = [0, e_ck, self._elites[d_ck]]
+                k = ck[0]
+                ck[0] = k + 1
             if eps is None:
-                eps_t = torch.randn((B, A), generator=self._gen, dtype=torch.float32, device=self.device)
+                eps_t = ck[1][k]
             else:
                 eps_t = self._scatter(eps, idx[:n], A)
             if model_inds is None:
-                draw = torch.randint(0, len(self._elites), (B,), generator=self._gen, device=self.device)
-                inds_t = self._elites[draw]
+                inds_t = ck[2][k]
             else:
                 inds_t = self._scatter(model_inds, idx[:n], None, torch.int32)
             if getattr(self, "_scratch", None) is None or self._scratch[0].shape[1] != B:

@@ -86,13 +86,6 @@ __device__ __forceinline__ double block_max(double v, double *sm) {
   return t;
 }
 
-// max for non-negative doubles through their (monotone) bit pattern
-__device__ __forceinline__ void atomic_max_nonneg(double *addr, double v) {
-  if (!(v > 0.0)) return;
-  atomicMax(reinterpret_cast<unsigned long long *>(addr),
-            static_cast<unsigned long long>(__double_as_longlong(v)));
-}
-
 // ---- reset -------------------------------------------------------------------------------------
 __global__ void reset_kernel(const cmbpo_rollout_t r) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;

@@ -535,10 +535,17 @@ class PE(TrainControl):
         return mean, var
 
     def predict(self, inputs, row_idx=None, out=None):
-        """Mean over ALL members (pe.py:338-343, 648-669); deterministic ensembles only."""
+        """Mean over ALL members (pe.py:338-343, 648-669); probabilistic ensembles return (mean, var) with the
+        disagreement of the member means added to the variance (pe.py:326-333; the member forward is the HIP kernel, the
+        reduction over the 7 members is two torch calls -- no caller of the training loop uses it)."""
         if self.is_probabilistic:
-            raise NotImplementedError("PE.predict of a probabilistic ensemble is not on the hot path "
-                                      "(FakeEnv uses predict_ensemble, fake_env.py:88-91)")
+            # pe.py:326-333: mean over members; var = mean member variance + variance of the member means
+            assert len(inputs.shape) == 2
+            x, was_np = _to_dev(inputs, self.device)
+            mean, var = self.predict_ensemble(x)
+            m2d = mean.mean(dim=0)
+            v2d = var.mean(dim=0) + ((mean - m2d) ** 2).mean(dim=0)
+            return (m2d.cpu().numpy(), v2d.cpu().numpy()) if was_np else (m2d, v2d)
         assert len(inputs.shape) == 2
         x, was_np = _to_dev(inputs, self.device)
         n = x.shape[0]

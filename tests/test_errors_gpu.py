@@ -38,8 +38,10 @@ def test_handles_reject_bad_shapes_and_unloaded_use(hip_lib):
         pe.predict_ensemble(torch.zeros(4, 9, device="cuda"))
     with pytest.raises(ValueError):                               # fc.py:92
         pe.predict_ensemble(torch.zeros(3, 4, 8, device="cuda"))
-    with pytest.raises(NotImplementedError):
-        pe.predict(x)                                             # PE.predict is the deterministic head's call
+    m2d, v2d = pe.predict(x)                                      # probabilistic: member mean + disagreement (pe.py:326-333)
+    me, ve = pe.predict_ensemble(x)
+    torch.testing.assert_close(m2d, me.mean(0))
+    torch.testing.assert_close(v2d, ve.mean(0) + me.var(0, unbiased=False), rtol=1e-5, atol=1e-7)
     with pytest.raises(ValueError):
         PE(8, 2, hidden_dims=(200, 200, 200), num_networks=3, num_elites=2, device="cuda:0")
     # trainer: wrong dims / oversized batch / unsupported loss

@@ -15,11 +15,12 @@ class _Space:
 
 
 class PointEnv:
-    """2-D point mass with drag: obs = [pos, vel, sin/cos of a clock]; reward = -|pos|; cost 1 outside |x| < 1."""
+    """2-D point mass with drag: obs = [pos, vel, sin/cos of a clock]; reward = -|pos - goal|; cost 1 outside |x| < 1."""
 
-    def __init__(self, seed=0):
+    def __init__(self, seed=0, goal=(0.0, 0.0)):
         self.observation_space, self.action_space = _Space(6), _Space(2)
         self.rng = np.random.RandomState(seed)
+        self.goal = np.asarray(goal, np.float64)
         self.t = 0
 
     def _obs(self):
@@ -34,7 +35,7 @@ class PointEnv:
         self.vel = 0.9 * self.vel + 0.1 * a + 0.01 * self.rng.standard_normal(2)
         self.pos = self.pos + 0.1 * self.vel
         self.t += 1
-        return self._obs(), -float(np.abs(self.pos).sum()), False, {"cost": float(abs(self.pos[0]) > 1.0)}
+        return self._obs(), -float(np.abs(self.pos - self.goal).sum()), False, {"cost": float(abs(self.pos[0]) > 1.0)}
 
     def close(self):
         pass
@@ -179,3 +180,42 @@ def test_cmbpo_learns_on_the_point_environment(hip_lib):
     first, last = float(np.mean(rets[:3])), float(np.mean(rets[-5:]))
     assert first < -18 and last > -8 and last > first + 12, (first, last, rets)
     assert max(kls) <= 0.01 * 1.5 and max(costs) <= 5.0
+
+
+def test_cpo_respects_the_cost_limit_model_free(hip_lib):
+    """Constraint handling, closed loop (model-free: the costs are the real environment's): the goal lies inside the
+    cost region (x = 2, cost 1 per step beyond |x| = 1), cost_lim = 5 per episode.  The return improves while the
+    episode cost settles at the limit instead of following the reward (an unconstrained policy collects ~30), and the
+    constrained cases of the update (not only the TRPO case 4) occur."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cmbpo_amd import synthetic
+    from cmbpo_amd.cmbpo import CMBPO
+    from cmbpo_amd.cpo_policy import CPOPolicy
+    from cmbpo_amd.cpo_sampler import CpoSampler
+    from cmbpo_amd.cpobuffer import CPOBuffer
+    np.random.seed(0)
+    env = PointEnv(seed=1, goal=(2.0, 0.0))
+    T = 50
+    policy = CPOPolicy(env.observation_space, env.action_space, a_hidden_layer_sizes=(128, 128),
+                       vf_hidden_layer_sizes=(128, 128), vf_ensemble_size=3, vf_elites=2, vf_activation="swish",
+                       vf_loss="MSE", vf_lr=1e-3, vf_epochs=4, vf_batch_size=256, device="cuda:0", max_path_length=T,
+                       cost_lim=5.0, target_kl=0.01, discount=0.97, lam=0.95)
+    policy.set_params(synthetic.policy_params(np.random.default_rng(2), 6, 2, 128))
+    rng = np.random.RandomState(1)
+    policy.v.init_weights(rng)
+    policy.vc.init_weights(rng)
+    buf = CPOBuffer(4000, 200000, env.observation_space, env.action_space)
+    epochs = 32
+    algo = CMBPO(env, policy, buf, sampler=CpoSampler(max_path_length=T), task="default", n_env_interacts=10 ** 9,
+                 eval_every_n_steps=1, use_model=False, batch_size_policy=4000, n_epochs=epochs)
+    rets, costs, cases = [], [], []
+    for k, d in enumerate(algo.train()):
+        rets.append(d["RetEpAverage"]); costs.append(d["CostEpAverage"]); cases.append(d["OptimCase"])
+        if k + 1 >= epochs:
+            break
+    first, last = float(np.mean(rets[:3])), float(np.mean(rets[-5:]))
+    tail_cost = float(np.mean(costs[-10:]))
+    assert last > first + 20, (first, last)
+    assert 2.0 <= tail_cost <= 8.0, (tail_cost, costs)            # settles at the limit of 5, far from the ~30 of the goal
+    assert any(c < 4 for c in cases), cases

@@ -1,5 +1,5 @@
 """Dev tool: does the whole algorithm learn?  CMBPO on the toy point-mass environment of tests/test_cmbpo_loop_gpu.py,
-printing the average episode return / cost per epoch.  python tools/run_loop_point.py [use_model 0|1] [epochs]"""
+printing the average episode return / cost per epoch.  python tools/run_loop_point.py [use_model 0|1] [epochs] [goal_x]"""
 import os
 import sys
 
@@ -21,7 +21,8 @@ def main():
     use_model = bool(int(sys.argv[1])) if len(sys.argv) > 1 else True
     epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 30
     np.random.seed(0)
-    env = PointEnv(seed=1)
+    goal = (float(sys.argv[3]), 0.0) if len(sys.argv) > 3 else (0.0, 0.0)     # goal x > 1 lies in the cost region
+    env = PointEnv(seed=1, goal=goal)
     T = 50
     policy = CPOPolicy(env.observation_space, env.action_space, a_hidden_layer_sizes=(128, 128),
                        vf_hidden_layer_sizes=(128, 128), vf_ensemble_size=3, vf_elites=2, vf_activation="swish",

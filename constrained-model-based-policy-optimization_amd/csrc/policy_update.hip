@@ -643,6 +643,7 @@ extern "C" int cmbpo_pi_create(cmbpo_pi_t **out, int obs_dim, int hidden, int ac
 
 extern "C" void cmbpo_pi_destroy(cmbpo_pi_t *h) {
   if (!h) return;
+  cmbpo_pi_cg_release(h);   // a cached CG graph holds this handle's buffers in its kernel arguments
   if (h->blob) (void)hipFree(h->blob);
   if (h->parts) (void)hipFree(h->parts);
   if (h->cg_z) (void)hipFree(h->cg_z);

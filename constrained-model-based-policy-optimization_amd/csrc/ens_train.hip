@@ -1216,6 +1216,9 @@ extern "C" int cmbpo_trainer_create(cmbpo_trainer_t **out, cmbpo_mlp_t *m, int m
     if (const char *env = getenv("CMBPO_WGRAD_KS")) {   // tuning aid: grid K split of the square layer
       if (l == 1 && atoi(env) > 0) ks = atoi(env);
     }
+    if (const char *env = getenv("CMBPO_WGRAD_KS_NARROW")) {   // ... and of the two narrow layers
+      if (l != 1 && atoi(env) > 0) ks = atoi(env);
+    }
     const int max_ks = max_batch / 32 < 1 ? 1 : max_batch / 32;
     if (ks > max_ks) ks = max_ks;
     if (ks > 16) ks = 16;

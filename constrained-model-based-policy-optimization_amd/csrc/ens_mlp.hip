@@ -433,6 +433,40 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
         if (rows[b] < 0) continue;
         p.out0[((size_t)e * n_rows + row0 + b) * ow + n] = reduced(b, n);
       }
+      if (p.tr_loss_part) {
+        // this tile's share of the loss statistics (sum (m - t)^2, sum (var - mse)^2, sum lv^2): the backward kernel
+        // adds the tiles' partials in a fixed order, so the training step needs no separate reduction kernels
+        const int D = p.tr_tdim;
+        const bool prob = ow == 2 * D;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int i = tid; i < BB * D; i += kThreads) {
+          const int b = i / D, d = i - b * D;
+          const int r = rows[b];
+          if (r < 0) continue;
+          float t = p.tr_targets[(size_t)r * D + d];
+          if (p.out_mu) t = (t - p.out_mu[d]) / p.out_sig[d];
+          const float diff = reduced(b, d) - t;
+          const float mse = diff * diff;
+          s0 += (double)mse;
+          if (prob) {
+            const float lv = reduced(b, D + d);
+            const float dv = expf(lv) - mse;
+            s1 += (double)(dv * dv);
+            s2 += (double)(lv * lv);
+          }
+        }
+        __shared__ double s_loss[3][kWaves];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          s0 += __shfl_down(s0, o, 64);
+          s1 += __shfl_down(s1, o, 64);
+          s2 += __shfl_down(s2, o, 64);
+        }
+        if (lane == 0) { s_loss[0][wave] = s0; s_loss[1][wave] = s1; s_loss[2][wave] = s2; }
+        __syncthreads();
+        if (tid < 3)
+          p.tr_loss_part[(size_t)item * 3 + tid] = (s_loss[tid][0] + s_loss[tid][1]) + (s_loss[tid][2] + s_loss[tid][3]);
+      }
     } else if constexpr (HEAD == CMBPO_HEAD_DETMEAN) {
       const int out = p.out_dim;
       if (tid < BB * out) {

@@ -42,6 +42,9 @@ struct MlpKernelArgs {
   float *tr_x;                 // [E][n_rows][in_pad]  scaled inputs
   float *tr_h1, *tr_g1;        // [E][n_rows][HID]     swish(z1), swish'(z1)
   float *tr_h2, *tr_g2;        // [E][n_rows][HID]
+  const float *tr_targets;     // [N][tr_tdim] regression targets (rows gathered like the inputs); with tr_loss_part
+  int tr_tdim;
+  double *tr_loss_part;        // [items][3] per-tile loss statistics (nullptr: not wanted)
 };
 
 struct cmbpo_mlp {

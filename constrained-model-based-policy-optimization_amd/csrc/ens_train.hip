@@ -10,8 +10,8 @@
 //   models/pens/pe.py:543-551           inputs[batch_idxs]: the per-member bootstrap gather (done in the kernel)
 //
 // One step = training forward (ens_mlp_kernel<HEAD_TRAIN>: raw outputs + exported activations and swish
-// derivatives) -> loss sums -> d(loss)/d(output) -> fused backward chain (two transposed-weight GEMMs, the
-// delta of the middle layer never leaves the CU un-multiplied) -> three weight-gradient GEMMs with the batch as
+// derivatives + per-tile loss statistics) -> fused backward chain (d(loss)/d(output) computed while its tile is
+// staged, then two transposed-weight GEMMs; the delta of the middle layer never leaves the CU un-multiplied) -> three weight-gradient GEMMs with the batch as
 // the K dimension (fp32 MFMA, split-K partials, bias gradients as column sums of the same operands; no atomics:
 // the step is bitwise reproducible; one launch for the 512-wide ensembles) -> Adam with the TensorFlow update
 // rule, which also re-packs the new weights into the MFMA layouts the forward / backward kernels read (the master
@@ -88,38 +88,6 @@ __global__ __launch_bounds__(kThreads) void loss_sums_kernel(const LossArgs p) {
   }
 }
 
-// MSPE (pe.py:921-973): total_e = mean (m - t)^2 + ratio * mean (var - sg(mse))^2 + 0.05 * mean_all lv^2, with
-// ratio = 0.05 * mean_all(mse) / mean_all((var - mse)^2) a constant of the step; train_loss = sum_e total_e, so the
-// regulariser (a scalar broadcast onto every member) counts E times.
-// MSE (pe.py:911-919): total_e = mean 0.5 (o - t)^2.
-__global__ __launch_bounds__(kThreads) void loss_delta_kernel(const LossArgs p) {
-  const size_t total = (size_t)p.E * p.B * p.OPk;
-  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
-  if (i >= total) return;
-  const int n = (int)(i % p.OPk);
-  const size_t eb = i / p.OPk;
-  const int b = (int)(eb % p.B), e = (int)(eb / p.B);
-  const float inv_bd = 1.0f / ((float)p.B * (float)p.D);
-  float d = 0.0f;
-  if (n < p.O) {
-    const float *orow = p.o + ((size_t)e * p.B + b) * p.O;
-    if (!p.prob) {
-      d = (orow[n] - scaled_target(p, e, b, n)) * inv_bd;
-    } else if (n < p.D) {
-      d = 2.0f * (orow[n] - scaled_target(p, e, b, n)) * inv_bd;
-    } else {
-      double tm = 0.0, tv = 0.0;
-      for (int k = 0; k < p.E; ++k) { tm += p.sums[k]; tv += p.sums[p.E + k]; }
-      const float ratio = (float)(0.05 * tm / tv);
-      const int dd = n - p.D;
-      const float diff = orow[dd] - scaled_target(p, e, b, dd);
-      const float lv = orow[n], var = expf(lv);
-      d = (2.0f * ratio * (var - diff * diff) * var + 0.1f * lv) * inv_bd;
-    }
-  }
-  p.d3[i] = d;
-}
-
 // `self.loss` of the reference for n rows seen so far: per-member 0.5 * mean (mean - t)^2
 __global__ void loss_finalize_kernel(const double *sums, int E, double inv_count, float *out) {
   const int e = threadIdx.x;
@@ -138,6 +106,14 @@ struct BwdArgs {
   const float *d3, *g2, *g1;
   float *d2, *d1;
   int B, OPk;
+  // fused output delta (d3 == nullptr on entry is not used: `fuse` selects): d(train_loss)/d(raw output) computed while
+  // the tile is staged, from the raw outputs, the gathered targets and the forward's per-tile loss statistics
+  int fuse, prob, O, D, n_items;
+  const float *o, *targets, *out_mu, *out_sig;
+  const int32_t *idx;
+  int idx_stride;
+  const double *loss_part;   // [n_items][3]
+  float *d3_out;             // [E][B][OPk], written for the weight-gradient kernel
 };
 
 template <int HID>
@@ -149,12 +125,66 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdArgs p)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int e = blockIdx.y, row0 = blockIdx.x * BB;
   const int kgo = p.OPk / 8;
-  {
+  if (!p.fuse) {
     float *xf = reinterpret_cast<float *>(xbuf);
     for (int i = tid; i < BB * p.OPk; i += kThreads) {
       const int b = i / p.OPk, k = i - b * p.OPk;
       float v = 0.0f;
       if (row0 + b < p.B) v = p.d3[((size_t)e * p.B + row0 + b) * p.OPk + k];
+      xf[((k >> 2) * BB + b) * 4 + (k & 3)] = v;
+    }
+  } else {
+    // Output deltas d(train_loss)/d(raw output).
+    // MSPE (pe.py:921-973): total_e = mean (m - t)^2 + ratio * mean (var - sg(mse))^2 + 0.05 * mean_all lv^2, with
+    // ratio = 0.05 * mean_all(mse) / mean_all((var - mse)^2) a constant of the step; train_loss = sum_e total_e, so the
+    // regulariser (a scalar broadcast onto every member) counts E times.
+    // MSE (pe.py:911-919): total_e = mean 0.5 (o - t)^2.
+    // The two sums behind `ratio` come from the forward's per-tile statistics, added here in tile order by every
+    // workgroup (same order everywhere: reproducible).
+    __shared__ double s_tot[2][kThreads / 64];
+    float ratio = 0.0f;
+    if (p.prob) {
+      double tm = 0.0, tv = 0.0;
+      for (int w = tid; w < p.n_items; w += kThreads) {
+        tm += p.loss_part[(size_t)w * 3];
+        tv += p.loss_part[(size_t)w * 3 + 1];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        tm += __shfl_down(tm, o, 64);
+        tv += __shfl_down(tv, o, 64);
+      }
+      if (lane == 0) { s_tot[0][wave] = tm; s_tot[1][wave] = tv; }
+      __syncthreads();
+      tm = (s_tot[0][0] + s_tot[0][1]) + (s_tot[0][2] + s_tot[0][3]);
+      tv = (s_tot[1][0] + s_tot[1][1]) + (s_tot[1][2] + s_tot[1][3]);
+      ratio = (float)(0.05 * tm / tv);
+    }
+    const float inv_bd = 1.0f / ((float)p.B * (float)p.D);
+    float *xf = reinterpret_cast<float *>(xbuf);
+    for (int i = tid; i < BB * p.OPk; i += kThreads) {
+      const int b = i / p.OPk, k = i - b * p.OPk;
+      float v = 0.0f;
+      const int row = row0 + b;
+      if (row < p.B) {
+        if (k < p.O) {
+          const float *orow = p.o + ((size_t)e * p.B + row) * p.O;
+          const int src = p.idx ? p.idx[(size_t)e * p.idx_stride + row] : row;
+          const int dd = (k < p.D) ? k : k - p.D;
+          float t = p.targets[(size_t)src * p.D + dd];
+          if (p.out_mu) t = (t - p.out_mu[dd]) / p.out_sig[dd];
+          const float diff = orow[dd] - t;
+          if (!p.prob) {
+            v = diff * inv_bd;
+          } else if (k < p.D) {
+            v = 2.0f * diff * inv_bd;
+          } else {
+            const float lv = orow[k], var = expf(lv);
+            v = (2.0f * ratio * (var - diff * diff) * var + 0.1f * lv) * inv_bd;
+          }
+        }
+        p.d3_out[((size_t)e * p.B + row) * p.OPk + k] = v;
+      }
       xf[((k >> 2) * BB + b) * 4 + (k & 3)] = v;
     }
   }
@@ -970,6 +1000,7 @@ struct cmbpo_trainer {
   float *x, *h1, *g1, *h2, *g2, *o, *d3, *d2, *d1;
   float *parts[3], *dB[3];
   double *sums;
+  double *loss_part;             // [E * ceil(max_batch / 32)][3] per-tile loss statistics of the training forward
   size_t wsize[3], bsize[3];
 };
 
@@ -1158,13 +1189,14 @@ int launch_fused(cmbpo_trainer *t, const float *d_inputs, const float *d_targets
 }
 
 int run_forward(cmbpo_trainer *t, const float *d_inputs, const int32_t *d_idx, int idx_stride, int rows, bool exports,
-                hipStream_t s) {
+                hipStream_t s, const float *d_targets = nullptr) {
   MlpKernelArgs a{};
   a.obs = d_inputs; a.obs_dim = t->I; a.act = nullptr; a.act_dim = 0;
   a.row_idx = d_idx; a.row_idx_stride = idx_stride;
   a.n_rows_dev = nullptr; a.n_rows = rows; a.ld_rows = rows;
   a.out0 = t->o;
   if (exports) { a.tr_x = t->x; a.tr_h1 = t->h1; a.tr_g1 = t->g1; a.tr_h2 = t->h2; a.tr_g2 = t->g2; }
+  if (d_targets) { a.tr_targets = d_targets; a.tr_tdim = t->D; a.tr_loss_part = t->loss_part; }
   return cmbpo_internal_launch_mlp(t->m, a, s, CMBPO_HEAD_TRAIN);
 }
 
@@ -1239,6 +1271,7 @@ extern "C" int cmbpo_trainer_create(cmbpo_trainer_t **out, cmbpo_mlp_t *m, int m
                og2 = take(rows * H), oo = take(rows * t->O), od3 = take(rows * t->OPk), od2 = take(rows * H),
                od1 = take(rows * H);
   const size_t osums = take(2 * 3 * (size_t)E);   // doubles
+  const size_t olp = take(2 * 3 * (size_t)E * cmbpo_ceil_div(max_batch, 32));   // doubles
   hipError_t err = hipMalloc(reinterpret_cast<void **>(&t->pool), off * sizeof(float));
   if (err != hipSuccess) {
     cmbpo_set_error("cmbpo_trainer_create: hipMalloc(%zu) failed: %s", off * sizeof(float), hipGetErrorString(err));
@@ -1262,6 +1295,7 @@ extern "C" int cmbpo_trainer_create(cmbpo_trainer_t **out, cmbpo_mlp_t *m, int m
   t->x = P + ox; t->h1 = P + oh1; t->g1 = P + og1; t->h2 = P + oh2; t->g2 = P + og2;
   t->o = P + oo; t->d3 = P + od3; t->d2 = P + od2; t->d1 = P + od1;
   t->sums = reinterpret_cast<double *>(P + osums);
+  t->loss_part = reinterpret_cast<double *>(P + olp);
   *out = t;
   return CMBPO_OK;
 }
@@ -1398,25 +1432,23 @@ extern "C" int cmbpo_trainer_step(cmbpo_trainer_t *t, const float *d_inputs, int
     return launch_update(t, 1, (float)lr_f, s);
   }
 
-  int rc = run_forward(t, d_inputs, d_idx, idx_stride, batch, true, s);
+  // training forward (+ per-tile loss statistics) -> backward chain (+ output deltas) -> weight gradients -> Adam
+  int rc = run_forward(t, d_inputs, d_idx, idx_stride, batch, true, s, d_targets);
   if (rc != CMBPO_OK) return rc;
-
-  LossArgs l{};
-  fill_loss_args(t, l, d_targets, d_idx, idx_stride, batch);
-  if (t->prob) {   // the MSE gradient needs no batch statistic
-    CMBPO_HIP_CHECK(hipMemsetAsync(t->sums, 0, 3 * (size_t)E * sizeof(double), s));
-    const int gx = min(cmbpo_ceil_div(batch * t->D, kThreads), 64);
-    hipLaunchKernelGGL(loss_sums_kernel, dim3(gx, E), dim3(kThreads), 0, s, l);
-  }
-  const size_t total = (size_t)E * batch * t->OPk;
-  hipLaunchKernelGGL(loss_delta_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, l);
-  CMBPO_HIP_CHECK(hipGetLastError());
 
   BwdArgs b{};
   b.wpb2 = reinterpret_cast<const f32x4 *>(t->wpb2); b.wpb1 = reinterpret_cast<const f32x4 *>(t->wpb1);
   b.wpb2_stride = (size_t)(H / 32) * (t->OPk / 8) * 64; b.wpb1_stride = (size_t)(H / 32) * (H / 8) * 64;
   b.d3 = t->d3; b.g2 = t->g2; b.g1 = t->g1; b.d2 = t->d2; b.d1 = t->d1;
   b.B = batch; b.OPk = t->OPk;
+  {
+    cmbpo_mlp *m = t->m;
+    b.fuse = 1; b.prob = t->prob; b.O = t->O; b.D = t->D; b.n_items = E * cmbpo_ceil_div(batch, 32);
+    b.o = t->o; b.targets = d_targets; b.idx = d_idx; b.idx_stride = idx_stride;
+    b.out_mu = m->has_out_scaler ? m->d_blob + m->off_out_mu : nullptr;
+    b.out_sig = m->has_out_scaler ? m->d_blob + m->off_out_var : nullptr;
+    b.loss_part = t->loss_part; b.d3_out = t->d3;
+  }
   const size_t lds = ((size_t)H / 4 * 32 + (size_t)t->OPk / 4 * 32) * sizeof(f32x4);
   const int tiles = cmbpo_ceil_div(batch, 32);
   rc = (H == 512) ? launch_bwd<512>(b, tiles, E, lds, s) : launch_bwd<128>(b, tiles, E, lds, s);

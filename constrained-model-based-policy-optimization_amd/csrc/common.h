@@ -30,3 +30,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static inline int cmbpo_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// tanh as 1 - 2 / (1 + e^{2x}) with the hardware exp / rcp (absolute error ~1e-7, saturates correctly at +-1; the libm
+// tanhf is ~30 VALU instructions per value, and VALU work next to a partner wave's fp32 MFMAs is the scarce resource of
+// the 128-wide kernels' epilogues)
+__device__ __forceinline__ float cmbpo_fast_tanh(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
+}

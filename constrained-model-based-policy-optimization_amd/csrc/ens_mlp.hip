@@ -57,7 +57,7 @@ __device__ __forceinline__ float activate(float x) {
     // the epilogue is VALU work that competes with the partner wave's MFMA issue.
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
   } else {
-    return tanhf(x);
+    return cmbpo_fast_tanh(x);
   }
 }
 

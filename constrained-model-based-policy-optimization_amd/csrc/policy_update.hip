@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
     {
       f32x16 hv;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hv[r] = tanhf(acc[0][0][r]);
+      for (int r = 0; r < 16; ++r) hv[r] = cmbpo_fast_tanh(acc[0][0][r]);
       store_tile_R(hv, wave * 32, h1R, RS, lane);
     }
     __syncthreads();
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
     {
       f32x16 hv;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hv[r] = tanhf(acc[0][0][r]);
+      for (int r = 0; r < 16; ++r) hv[r] = cmbpo_fast_tanh(acc[0][0][r]);
       store_tile_R(hv, wave * 32, h2R, RS, lane);
     }
     __syncthreads();

@@ -774,7 +774,7 @@ __global__ __launch_bounds__(kThreads, 1) void fused_mse_step_kernel(const Fused
       f32x16 hv;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float z = acc[r], sg = 1.0f / (1.0f + __expf(-z));
+        const float z = acc[r], sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
         hv[r] = z * sg;
         g1[r] = sg * (1.0f + z * (1.0f - sg));
       }
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(kThreads, 1) void fused_mse_step_kernel(const Fused
       f32x16 hv;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float z = acc[r], sg = 1.0f / (1.0f + __expf(-z));
+        const float z = acc[r], sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
         hv[r] = z * sg;
         g2[r] = sg * (1.0f + z * (1.0f - sg));
       }

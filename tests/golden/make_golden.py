@@ -323,7 +323,13 @@ def gen_sampler_traces(out):
         # no statics entry (Hopper): never terminates, bool zero cost; tight budget
         "g5_trace_hopper_budget": dict(seed=9, task="HopperSafe-v2", B=50, T=15, hidden=128, dkl_lim=float("inf"),
                                        budget=333, mode="uncertainty"),
+        # widest shapes (obs 47 / act 17: 64 inputs, 96 raw outputs) at the production width, uncertainty deaths
+        "g5_trace_humanoid_512": dict(seed=11, task="HumanoidSafe-v2", B=70, T=7, hidden=512, dkl_lim=None, budget=None,
+                                      mode="uncertainty"),
     }
+    only = os.environ.get("CMBPO_GOLDEN_TRACES")
+    if only:
+        traces = {k: v for k, v in traces.items() if k in only.split(",")}
     for name, cfg in traces.items():
         if cfg["dkl_lim"] is None:
             # calibrate a limit that kills a fraction of the branches over the rollout
@@ -693,7 +699,10 @@ def gen_cpobuffer_archive(out):
 
 
 if __name__ == "__main__":
-    if "--archive-only" in sys.argv:
+    if "--traces-only" in sys.argv:
+        install_stubs()
+        gen_sampler_traces(HERE)
+    elif "--archive-only" in sys.argv:
         install_stubs()
         gen_cpobuffer_archive(HERE)
     elif "--loop-helpers-only" in sys.argv:

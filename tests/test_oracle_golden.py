@@ -95,7 +95,8 @@ def replay_trace(g, make_world):
     return orc, np.array(alive), np.array(totals), np.array(ratios), res, diag
 
 
-TRACES = ["g5_trace_ant_unc", "g5_trace_ant_term", "g5_trace_hcs_sched", "g5_trace_hopper_budget"]
+TRACES = ["g5_trace_ant_unc", "g5_trace_ant_term", "g5_trace_hcs_sched", "g5_trace_hopper_budget",
+          "g5_trace_humanoid_512"]
 
 
 @pytest.mark.parametrize("name", TRACES)

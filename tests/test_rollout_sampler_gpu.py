@@ -67,7 +67,7 @@ def _need_gpu():
 
 
 @pytest.mark.parametrize("name", ["g5_trace_ant_unc", "g5_trace_ant_term", "g5_trace_hcs_sched",
-                                  "g5_trace_hopper_budget"])
+                                  "g5_trace_hopper_budget", "g5_trace_humanoid_512"])
 def test_hip_sampler_reproduces_reference_trace(hip_lib, name):
     _need_gpu()
     from worlds import build_world

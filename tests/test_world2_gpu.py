@@ -104,7 +104,8 @@ def _worker(rank, world, port, name, out_dir):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("name", ["g5_trace_ant_unc", "g5_trace_hopper_budget", "g5_trace_ant_term"])
+@pytest.mark.parametrize("name", ["g5_trace_ant_unc", "g5_trace_hopper_budget", "g5_trace_ant_term",
+                                  "g5_trace_humanoid_512"])
 def test_sharded_rollout_reproduces_reference_trace(hip_lib, tmp_path, name):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")

@@ -66,6 +66,7 @@ class PolicyOps:
         self.D, self.A = int(obs_dim), int(act_dim)
         self.comm = comm
         self.use_graph = True       # CG iterations as a cached hipGraph (single-GPU jobs)
+        self.keep_activations = True    # Fisher-vector products reuse the hidden activations loss_grad computed
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().cmbpo_pi_create(C.byref(self._h), self.D, int(hidden), self.A), "cmbpo_pi_create")
@@ -122,6 +123,9 @@ class PolicyOps:
         for name, t in zip(("obs", "act", "adv", "cadv", "logp_old", "cost", "mu_old", "logstd_old"), ts):
             setattr(b, name, t.data_ptr())
         self.n_local = n
+        # a new feed: whatever activations the handle saved belong to the previous one
+        _lib.check(_lib.lib().cmbpo_pi_keep_activations(self._h, 1 if self.keep_activations else 0),
+                   "cmbpo_pi_keep_activations")
         self.n_global = n if self.comm is None else int(self.comm.all_reduce_host([n])[0])
 
     def _reduce(self, *tensors):

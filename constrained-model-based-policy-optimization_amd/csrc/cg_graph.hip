@@ -24,6 +24,7 @@ struct CgKey {
   float damping;
   int iters, P;
   hipStream_t s;
+  const void *act;   // saved activations the captured Fisher-vector products read (or NULL)
 };
 
 struct CgGraph {
@@ -50,6 +51,7 @@ extern "C" int cmbpo_pi_cg_solve(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, const
   memset(&k, 0, sizeof(k));
   k.h = h; memcpy(&k.b, b, sizeof(k.b)); k.vec = d_vec; k.x = d_x; k.r = d_r; k.p = d_p; k.scal = d_scal;
   k.inv_n = inv_n; k.damping = damping; k.iters = iters; k.P = cmbpo_pi_num_params(h); k.s = (hipStream_t)stream;
+  k.act = cmbpo_pi_act_token(h, b);
   if (int rc = cmbpo_cg_init(k.P, d_b, d_x, d_r, d_p, d_scal, stream)) return rc;
   if (int rc = iteration(h, k)) return rc;            // eager: also performs any one-time kernel attribute set-up
   if (iters == 1) return cmbpo_pi_cg_commit(d_scal, stream);

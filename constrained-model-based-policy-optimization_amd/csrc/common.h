@@ -7,6 +7,9 @@
 #include "../../include/cmbpo_hip.h"
 
 void cmbpo_set_error(const char *fmt, ...);
+// the saved-activation block a Fisher-vector product on this batch would read (NULL: recompute); part of the key of a
+// captured CG graph, whose kernel arguments contain it
+const void *cmbpo_pi_act_token(const cmbpo_pi_t *h, const cmbpo_pi_batch_t *b);
 
 #define CMBPO_HIP_CHECK(expr)                                                  \
   do {                                                                         \

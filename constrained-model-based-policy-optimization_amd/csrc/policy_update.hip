@@ -56,6 +56,8 @@ struct PiArgs {
   float *part;      // [grid][part_ld] per-workgroup partial sums
   int part_ld;
   double *sums;     // [8]  n, sum ratio*adv, sum ratio*cadv, sum kl, sum cost
+  const f32x4 *cache_r;   // FVP: saved hidden activations of this batch ([tile][h1 | h2][32][128]) or NULL (recompute)
+  f32x4 *cache_w;         // GRAD: where to save them, or NULL
 };
 
 // ---- packing (device side, so set_params / FVP directions never visit the host) -------------------
@@ -116,6 +118,8 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
   const int n_tiles = (p.n + BB - 1) / BB;
+  constexpr int IMG4 = BB * HID / 4;    // float4s of one dense [32][128] activation image
+  const bool cached = (MODE == MODE_FVP) && p.cache_r != nullptr;
 
   // persistent accumulators
   f32x16 gW1[4], gW0[N_IT], gW2;
@@ -140,27 +144,57 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
       const int r = row0 + b;
       xR[b * XS + k] = (r < p.n && k < d.D) ? p.obs[(size_t)r * d.D + k] : 0.0f;
     }
-    __syncthreads();
-    // ---- forward ------------------------------------------------------------------------------------
     f32x16 acc[1][1];
-    acc[0][0] = load_bias(p.w.b0, wave * 32, lane);
-    mfma_layer<1, 1, true>(p.w.F0 + (size_t)wave * d.kg0 * 64, 0, 0, d.kg0, xR4, lane, acc, XS);
-    {
-      f32x16 hv;
+    if (cached) {
+      // ---- h1, h2 as cmbpo_pi_loss_grad left them (same parameters, same batch): identical bits to recomputing
+      // them, without the forward chain's 80 MFMAs and 8 K tanh per tile
+      const f32x4 *src = p.cache_r + (size_t)tile * (2 * IMG4);
+      f32x4 t1[4], t2[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hv[r] = cmbpo_fast_tanh(acc[0][0][r]);
-      store_tile_R(hv, wave * 32, h1R, RS, lane);
-    }
-    __syncthreads();
-    acc[0][0] = load_bias(p.w.b1, wave * 32, lane);
-    mfma_layer<1, 1, true>(p.w.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, h1R4, lane, acc, RS);
-    {
-      f32x16 hv;
+      for (int i = 0; i < 4; ++i) {
+        t1[i] = src[tid + kThreads * i];
+        t2[i] = src[IMG4 + tid + kThreads * i];
+      }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hv[r] = cmbpo_fast_tanh(acc[0][0][r]);
-      store_tile_R(hv, wave * 32, h2R, RS, lane);
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + kThreads * i, b = idx >> 5, c = idx & 31;
+        reinterpret_cast<f32x4 *>(h1R)[b * (RS / 4) + c] = t1[i];
+        reinterpret_cast<f32x4 *>(h2R)[b * (RS / 4) + c] = t2[i];
+      }
+      __syncthreads();
+    } else {
+      __syncthreads();
+      // ---- forward ----------------------------------------------------------------------------------
+      acc[0][0] = load_bias(p.w.b0, wave * 32, lane);
+      mfma_layer<1, 1, true>(p.w.F0 + (size_t)wave * d.kg0 * 64, 0, 0, d.kg0, xR4, lane, acc, XS);
+      {
+        f32x16 hv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[r] = cmbpo_fast_tanh(acc[0][0][r]);
+        store_tile_R(hv, wave * 32, h1R, RS, lane);
+      }
+      __syncthreads();
+      acc[0][0] = load_bias(p.w.b1, wave * 32, lane);
+      mfma_layer<1, 1, true>(p.w.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, h1R4, lane, acc, RS);
+      {
+        f32x16 hv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[r] = cmbpo_fast_tanh(acc[0][0][r]);
+        store_tile_R(hv, wave * 32, h2R, RS, lane);
+      }
+      __syncthreads();
+      if constexpr (MODE == MODE_GRAD) {
+        if (p.cache_w != nullptr) {
+          f32x4 *dst = p.cache_w + (size_t)tile * (2 * IMG4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int idx = tid + kThreads * i, b = idx >> 5, c = idx & 31;
+            dst[idx] = h1R4[b * (RS / 4) + c];
+            dst[IMG4 + idx] = h2R4[b * (RS / 4) + c];
+          }
+        }
+      }
     }
-    __syncthreads();
 
     if constexpr (MODE == MODE_FVP) {
       // ---- JVP chain: dh1 = (1-h1^2)(x dW0 + db0) ; dh2 = (1-h2^2)(dh1 W1 + h1 dW1 + db1) -----------
@@ -304,6 +338,13 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
     }
     __syncthreads();
     // ---- weight gradients: K = the tile's samples ---------------------------------------------------
+    float warm = 0.0f;
+    if constexpr (MODE == MODE_FVP) {
+      // touch one dword of each 128-B line of the NEXT tile's saved activations: they travel HBM -> L2 behind the
+      // 96 MFMAs below, and the loads at the top of the next iteration hit L2 (one VGPR instead of a 32-VGPR prefetch)
+      const int nxt = tile + gridDim.x;
+      if (cached && nxt < n_tiles) warm = reinterpret_cast<const float *>(p.cache_r + (size_t)nxt * (2 * IMG4))[tid * 32];
+    }
 #pragma unroll
     for (int J = 0; J < 4; ++J) wgrad_tile(gW1[J], h1R, RS, wave * 32, d2R, RS, J * 32, lane);
 #pragma unroll
@@ -318,6 +359,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
       for (int b = 0; b < BB; ++b) sb += img[b * RS + n];
       gbias += sb;
     }
+    asm volatile("" ::"v"(warm));   // the warm-up load must be issued, its value is not used
     __syncthreads();
   }
 
@@ -506,6 +548,14 @@ struct cmbpo_pi {
   size_t off_F0, off_F1, off_F2, off_B1, off_B2, off_b0, off_b1, off_b2, off_ls;
   int n_cu;
   bool has_params;
+  // hidden activations saved by cmbpo_pi_loss_grad for the Fisher-vector products of the same update
+  // (cmbpo_pi_keep_activations): [tile][h1 | h2][32][128] floats, grow-only
+  float *act;
+  size_t act_tiles;       // capacity
+  bool act_keep, act_valid;
+  const float *act_obs;   // the batch the saved activations belong to
+  int act_n;
+  long act_hits;          // Fisher-vector products that read the saved activations (diagnostics)
 };
 
 namespace {
@@ -592,7 +642,30 @@ int fill_args(cmbpo_pi *h, const cmbpo_pi_batch_t *b, PiArgs &a, const char *who
   a.n = b->n;
   a.obs = b->obs; a.act = b->act; a.adv = b->adv; a.cadv = b->cadv; a.logp_old = b->logp_old; a.cost = b->cost;
   a.mu_old = b->mu_old; a.ls_old = b->logstd_old;
+  a.cache_r = nullptr; a.cache_w = nullptr;
   return CMBPO_OK;
+}
+
+// the saved activations a Fisher-vector product on batch b may read, or NULL
+const f32x4 *act_for(const cmbpo_pi *h, const cmbpo_pi_batch_t *b) {
+  if (!h->act_keep || !h->act_valid || h->act == nullptr || b->obs != h->act_obs || b->n != h->act_n) return nullptr;
+  return reinterpret_cast<const f32x4 *>(h->act);
+}
+
+// make room for the activations of n samples; on failure the update simply recomputes them
+bool act_reserve(cmbpo_pi *h, int n) {
+  const size_t tiles = (size_t)cmbpo_ceil_div(n, BB);
+  if (h->act != nullptr && h->act_tiles >= tiles) return true;
+  h->act_valid = false;
+  if (h->act) (void)hipFree(h->act);      // synchronises: nothing in flight still reads the old block
+  h->act = nullptr; h->act_tiles = 0;
+  if (hipMalloc(reinterpret_cast<void **>(&h->act), tiles * 2 * BB * HID * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError();
+    h->act = nullptr;
+    return false;
+  }
+  h->act_tiles = tiles;
+  return true;
 }
 
 }  // namespace
@@ -618,6 +691,7 @@ extern "C" int cmbpo_pi_create(cmbpo_pi_t **out, int obs_dim, int hidden, int ac
   h->off_b0 = take(HID); h->off_b1 = take(HID); h->off_b2 = take(32); h->off_ls = take(32);
   h->pack_floats = off;
   h->has_params = false;
+  h->act = nullptr; h->act_tiles = 0; h->act_keep = false; h->act_valid = false; h->act_obs = nullptr; h->act_n = 0; h->act_hits = 0;
   hipDeviceProp_t prop;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
@@ -648,6 +722,7 @@ extern "C" void cmbpo_pi_destroy(cmbpo_pi_t *h) {
   if (h->parts) (void)hipFree(h->parts);
   if (h->cg_z) (void)hipFree(h->cg_z);
   if (h->cg_part) (void)hipFree(h->cg_part);
+  if (h->act) (void)hipFree(h->act);
   delete h;
 }
 
@@ -657,8 +732,20 @@ extern "C" int cmbpo_pi_set_params(cmbpo_pi_t *h, const float *d_flat, void *str
   CMBPO_REQUIRE(h != nullptr && d_flat != nullptr, "cmbpo_pi_set_params: NULL argument");
   if (int rc = do_pack(h, h->blob, d_flat, (hipStream_t)stream)) return rc;
   h->has_params = true;
+  h->act_valid = false;       // saved activations belong to the previous parameters
   return CMBPO_OK;
 }
+
+extern "C" int cmbpo_pi_keep_activations(cmbpo_pi_t *h, int enable) {
+  CMBPO_REQUIRE(h != nullptr, "cmbpo_pi_keep_activations: NULL handle");
+  h->act_keep = enable != 0;
+  h->act_valid = false;
+  return CMBPO_OK;
+}
+
+extern "C" long cmbpo_pi_saved_activation_uses(const cmbpo_pi_t *h) { return h ? h->act_hits : -1; }
+
+const void *cmbpo_pi_act_token(const cmbpo_pi_t *h, const cmbpo_pi_batch_t *b) { return (h && b) ? act_for(h, b) : nullptr; }
 
 extern "C" int cmbpo_pi_loss_grad(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, int which, float *d_vec, double *d_sums,
                                   void *stream) {
@@ -669,7 +756,11 @@ extern "C" int cmbpo_pi_loss_grad(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, int 
   hipStream_t s = (hipStream_t)stream;
   CMBPO_HIP_CHECK(hipMemsetAsync(d_sums, 0, 8 * sizeof(double), s));
   a.which = which; a.vec = d_vec; a.sums = d_sums;
-  return launch_pi<MODE_GRAD>(h, a, s);
+  const bool save = h->act_keep && act_for(h, b) == nullptr && act_reserve(h, b->n);
+  if (save) a.cache_w = reinterpret_cast<f32x4 *>(h->act);
+  if (int rc = launch_pi<MODE_GRAD>(h, a, s)) return rc;
+  if (save) { h->act_valid = true; h->act_obs = b->obs; h->act_n = b->n; }
+  return CMBPO_OK;
 }
 
 extern "C" int cmbpo_pi_fvp(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, const float *d_v, float *d_vec, void *stream) {
@@ -679,6 +770,8 @@ extern "C" int cmbpo_pi_fvp(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, const floa
   hipStream_t s = (hipStream_t)stream;
   if (int rc = do_pack(h, h->blob + h->pack_floats, d_v, s)) return rc;
   a.vec = d_vec; a.sums = nullptr;
+  a.cache_r = act_for(h, b);
+  h->act_hits += a.cache_r != nullptr;
   return launch_pi<MODE_FVP>(h, a, s);
 }
 
@@ -693,6 +786,8 @@ extern "C" int cmbpo_pi_cg_iter(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, double
   hipStream_t s = (hipStream_t)stream;
   if (int rc = do_pack(h, h->blob + h->pack_floats, d_p, s)) return rc;
   a.vec = nullptr; a.sums = nullptr;              // partial vectors only: cg_k1 adds them up
+  a.cache_r = act_for(h, b);
+  h->act_hits += a.cache_r != nullptr;            // (a captured replay counts once, at capture)
   if (int rc = launch_pi<MODE_FVP>(h, a, s)) return rc;
   const int P = h->d.P, n1 = cmbpo_ceil_div(P, 64), n2 = cmbpo_ceil_div(P, 256);
   double *pzp = h->cg_part, *rrp = h->cg_part + n1;

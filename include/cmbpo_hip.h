@@ -305,6 +305,21 @@ int cmbpo_pi_loss_grad(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, int which,
 int cmbpo_pi_fvp(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, const float *d_v,
                  float *d_vec, void *stream);
 
+/* The reference re-feeds the batch through the whole policy graph for every one
+ * of the 10-20 Hx evaluations of an update (cpo_policy.py:168, 550-552), although
+ * parameters and batch are fixed from flat_g to the end of the CG solves.  With
+ * enable != 0, cmbpo_pi_loss_grad saves the two hidden activation images of the
+ * batch (1 KB per sample, owned by the handle, grow-only) and every later
+ * Fisher-vector product on the same (obs pointer, n) reads them instead of
+ * recomputing the forward chain -- bit-identical results.  The saved images are
+ * dropped by cmbpo_pi_set_params and by any call of this function; the caller
+ * must not change the batch in place between loss_grad and the products.  Off by
+ * default; if the memory cannot be had the products silently recompute. */
+int cmbpo_pi_keep_activations(cmbpo_pi_t *h, int enable);
+/* Fisher-vector product launches that read saved activations so far (a launch
+ * captured into the CG graph counts once); diagnostics / tests. */
+long cmbpo_pi_saved_activation_uses(const cmbpo_pi_t *h);
+
 /* [d_kl, pi_loss, surr_cost] at the current parameters (set_and_eval,
  * cpo_policy.py:278-280): d_sums[8] = {n, sum ratio*adv, sum ratio*cadv,
  * sum_n sum_a kl, sum cost}. */

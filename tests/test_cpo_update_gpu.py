@@ -169,3 +169,49 @@ def test_cg_solve_graph_matches_eager_loop(hip_lib):
     ref = refupdate.cg(lambda v: graph.hvp(params, v, 0.1), b.cpu().numpy()) if hasattr(refupdate, "cg") else None
     if ref is not None:
         _close(outs[0], ref, rtol=2e-2, arel=2e-3)
+
+
+@pytest.mark.parametrize("D,A,n", [(29, 8, 5003), (47, 17, 500), (21, 3, 31)])
+def test_fvp_from_saved_activations_is_bit_identical(hip_lib, D, A, n):
+    """cmbpo_pi_keep_activations: the Fisher-vector products that read the hidden activations cmbpo_pi_loss_grad saved
+    == the ones that recompute the forward chain, bit for bit (eager products and the whole CG solve); the saved
+    images are dropped with the parameters they belong to."""
+    _need_gpu()
+    from cmbpo_amd import _lib
+    rng, params, batch, graph, ops = _setup(D, A, n, seed=7 * D + A)
+    uses = lambda: _lib.lib().cmbpo_pi_saved_activation_uses(ops._h)
+    v = rng.standard_normal(params.shape).astype(np.float32)
+    b = torch.from_numpy(rng.standard_normal(params.shape).astype(np.float32)).cuda()
+    hv_re = ops.fvp(v)                                   # nothing saved since set_params: recomputed
+    x_re = torch.zeros_like(b)
+    ops.cg_dev(b, x_re, 0.1)
+    assert uses() == 0
+    g0, _ = ops.loss_grad(0)                             # saves h1 / h2 of the batch
+    hv_sv = ops.fvp(v)
+    assert uses() == 1
+    np.testing.assert_array_equal(hv_sv, hv_re)
+    x_sv = torch.zeros_like(b)
+    ops.cg_dev(b, x_sv, 0.1)
+    assert uses() > 1
+    np.testing.assert_array_equal(x_sv.cpu().numpy(), x_re.cpu().numpy())
+    g1, _ = ops.loss_grad(0)                             # the gradient itself is unchanged by saving / not saving
+    np.testing.assert_array_equal(g0, g1)
+    # new parameters: the saved images are stale and must not be used
+    p2 = (params + 0.05 * rng.standard_normal(params.shape)).astype(np.float32)
+    ops.set_params(p2)
+    before = uses()
+    hv2 = ops.fvp(v)
+    assert uses() == before
+    ops.loss_grad(1)                                     # either gradient call saves
+    hv2_sv = ops.fvp(v)
+    assert uses() == before + 1
+    np.testing.assert_array_equal(hv2_sv, hv2)
+    assert np.max(np.abs(hv2 - hv_re)) > 0
+    # switched off: never read
+    ops.keep_activations = False
+    ops.bind(batch["obs"], batch["act"], batch["adv"], batch["cadv"], batch["logp_old"], batch["cost"],
+             batch["mu_old"], batch["log_std_old"])
+    ops.loss_grad(0)
+    before = uses()
+    np.testing.assert_array_equal(ops.fvp(v), hv2)
+    assert uses() == before

@@ -23,6 +23,7 @@ pol = CPOPolicy(S(D), S(A), a_hidden_layer_sizes=(128, 128), vf_hidden_layer_siz
                 vf_elites=2, vf_activation="swish", vf_loss="MSE", device="cuda:0", constrain_cost=constrained,
                 cost_lim=10.0, target_kl=0.01, max_path_length=T)
 dev = pol.device
+pol.ops.keep_activations = os.environ.get("CMBPO_KEEP_ACT", "1") != "0"   # A/B of the saved-activation products
 z = torch.zeros(N, device=dev)
 t = lambda a: torch.from_numpy(a).to(dev)
 buf = [t(batch["obs"]), t(batch["act"]), t(batch["adv"]), t(batch["cadv"]), z, z, t(batch["logp_old"]), z, z,

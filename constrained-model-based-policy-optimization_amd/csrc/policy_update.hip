@@ -132,17 +132,65 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
   float gb2p[4] = {0, 0, 0, 0}, glsp[4] = {0, 0, 0, 0};   // per (a = tid/32 + 8*it) partials over this thread's b
   double s_n = 0, s_ra = 0, s_rc = 0, s_kl = 0, s_cost = 0;
 
-  // zero the padded cotangent columns once (a in [A, 36)): nothing else ever writes them
+  // zero the padded cotangent columns (a in [A, 36)) and the padded input columns (k in [D, in_pad)) once: nothing
+  // else ever writes them
   for (int i = tid; i < BB * 36; i += kThreads) wR[i] = 0.0f;
+  for (int i = tid; i < BB * XS; i += kThreads) xR[i] = 0.0f;
   __syncthreads();
+
+  // The tile's observations are one contiguous block of 32 D floats: each thread keeps its <= 4 N_IT of them in
+  // registers, fetched one tile ahead (behind the weight-gradient MFMAs), so that staging never waits for HBM.
+  // (The 33..64-wide input variant has no registers to spare for it and stages straight from HBM.)
+  constexpr bool PRE = (N_IT == 1);
+  float xpre[4 * N_IT];
+  auto fetch_x = [&](int t) {
+    if constexpr (!PRE) return;
+    const size_t base = (size_t)t * BB * d.D;
+    const int lim = min(BB, p.n - t * BB) * d.D;      // rows past the batch end read as zeros
+#pragma unroll
+    for (int q = 0; q < 4 * N_IT; ++q) {
+      const int i = tid + q * kThreads;
+      xpre[q] = (i < lim) ? p.obs[base + i] : 0.0f;
+    }
+  };
+  if ((int)blockIdx.x < n_tiles) fetch_x(blockIdx.x);
+  // Fisher cotangent: its tile-invariant factors per action column, computed once (LDS: no registers to spare)
+  __shared__ float c_b2[32], c_e2[32];
+  if constexpr (MODE == MODE_FVP) {
+    if (tid < 32) {
+      c_b2[tid] = (tid < d.A) ? p.v.b2[tid] : 0.0f;
+      c_e2[tid] = (tid < d.A) ? 2.0f * expf(2.0f * p.w.ls[tid]) : 0.0f;
+    }
+    __syncthreads();
+  }
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int row0 = tile * BB;
-    // ---- stage x in the row layout (zero padded) ------------------------------------------------------
-    for (int i = tid; i < d.in_pad * BB; i += kThreads) {
-      const int b = i / d.in_pad, k = i - b * d.in_pad;
-      const int r = row0 + b;
-      xR[b * XS + k] = (r < p.n && k < d.D) ? p.obs[(size_t)r * d.D + k] : 0.0f;
+    // ---- stage x in the row layout ---------------------------------------------------------------------
+    if constexpr (PRE) {
+#pragma unroll
+      for (int q = 0; q < 4 * N_IT; ++q) {
+        const int i = tid + q * kThreads;
+        if (i < BB * d.D) {
+          const int b = i / d.D, k = i - b * d.D;
+          xR[b * XS + k] = xpre[q];
+        }
+      }
+    } else {
+      for (int i = tid; i < BB * d.D; i += kThreads) {
+        const int b = i / d.D, k = i - b * d.D;
+        xR[b * XS + k] = (row0 + b < p.n) ? p.obs[(size_t)row0 * d.D + i] : 0.0f;
+      }
+    }
+    if constexpr (MODE == MODE_EVAL) {   // (the other modes fetch ahead later, next to their weight-gradient MFMAs)
+      if (tile + (int)gridDim.x < n_tiles) fetch_x(tile + gridDim.x);
+    }
+    // the Fisher cotangent's log_std_old (first 8 action columns): requested now, used in the element phase, so
+    // that its HBM latency passes behind the JVP chain instead of between two barriers
+    float lso0 = 0.0f;
+    if constexpr (MODE == MODE_FVP) {
+      const int er0 = row0 + (tid & 31), a0 = tid >> 5;
+      if (a0 < d.A && er0 < p.n) lso0 = p.ls_old[(size_t)er0 * d.A + a0];
     }
     f32x16 acc[1][1];
     if (cached) {
@@ -207,10 +255,11 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
         for (int r = 0; r < 16; ++r) o[r] = (1.0f - hh[r] * hh[r]) * acc[0][0][r];
         store_tile_R(o, wave * 32, u1R, RS, lane);
       }
-      __syncthreads();
+      // the h1 dW1 half does not need dh1: it runs ahead of the barrier and absorbs the waves' skew
       acc[0][0] = load_bias(p.v.b1, wave * 32, lane);
-      mfma_layer<1, 1, true>(p.w.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, u1R4, lane, acc, RS);
       mfma_layer<1, 1, true>(p.v.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, h1R4, lane, acc, RS);
+      __syncthreads();
+      mfma_layer<1, 1, true>(p.w.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, u1R4, lane, acc, RS);
       {
         const f32x16 hh = load_tile_R(h2R, RS, wave * 32, lane);
         f32x16 o;
@@ -218,11 +267,11 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
         for (int r = 0; r < 16; ++r) o[r] = (1.0f - hh[r] * hh[r]) * acc[0][0][r];
         store_tile_R(o, wave * 32, u2R, RS, lane);
       }
-      __syncthreads();   // dh2 complete; every wave is done reading dh1 (u1R becomes the reduction image)
-      // dmu = dh2 W2 + h2 dW2 (+ db2): K split over the 4 waves
+      // dmu = dh2 W2 + h2 dW2 (+ db2): K split over the 4 waves; the h2 dW2 half ahead of the barrier
       zero(acc[0][0]);
-      mfma_layer<1, 1, true>(p.w.F2, 0, wave * 4, wave * 4 + 4, u2R4, lane, acc, RS);
       mfma_layer<1, 1, true>(p.v.F2, 0, wave * 4, wave * 4 + 4, h2R4, lane, acc, RS);
+      __syncthreads();   // dh2 complete; every wave is done reading dh1 (u1R becomes the reduction image)
+      mfma_layer<1, 1, true>(p.w.F2, 0, wave * 4, wave * 4 + 4, u2R4, lane, acc, RS);
     } else {
       // mu = h2 W2 (+ b2): K split over the 4 waves
       zero(acc[0][0]);
@@ -250,13 +299,14 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
         m += red[(2 * 32 + a) * RED_LD + eb];
         m += red[(3 * 32 + a) * RED_LD + eb];
         if constexpr (MODE == MODE_FVP) {
-          m += p.v.b2[a];
+          m += c_b2[a];
           float cot = 0.0f;
           if (valid) {
             // d2 KL / d mu^2 = 1 / (exp(2 ls_old) + eps)   (network/ac_network.py:52-53)
-            const float v1 = expf(2.0f * p.ls_old[(size_t)er * d.A + a]) + 1e-8f;
+            const float lso = (it == 0) ? lso0 : p.ls_old[(size_t)er * d.A + a];
+            const float v1 = expf(2.0f * lso) + 1e-8f;
             cot = m / v1;
-            glsp[it] += 2.0f * expf(2.0f * p.w.ls[a]) / v1;     // d2 KL / d log_std^2
+            glsp[it] += c_e2[a] / v1;                           // d2 KL / d log_std^2 = 2 exp(2 ls) / (...)
           }
           wR[eb * 36 + a] = cot;
           gb2p[it] += cot;
@@ -336,20 +386,25 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
       for (int r = 0; r < 16; ++r) o[r] = (1.0f - hh[r] * hh[r]) * acc[0][0][r];
       store_tile_R(o, wave * 32, d1R, RS, lane);     // the reduction image is dead (element phase barrier)
     }
-    __syncthreads();
     // ---- weight gradients: K = the tile's samples ---------------------------------------------------
     float warm = 0.0f;
+    if constexpr (MODE != MODE_EVAL) {
+      if (tile + (int)gridDim.x < n_tiles) fetch_x(tile + gridDim.x);
+    }
     if constexpr (MODE == MODE_FVP) {
       // touch one dword of each 128-B line of the NEXT tile's saved activations: they travel HBM -> L2 behind the
       // 96 MFMAs below, and the loads at the top of the next iteration hit L2 (one VGPR instead of a 32-VGPR prefetch)
       const int nxt = tile + gridDim.x;
       if (cached && nxt < n_tiles) warm = reinterpret_cast<const float *>(p.cache_r + (size_t)nxt * (2 * IMG4))[tid * 32];
     }
+    // dW1 and dW2 need delta2 / the cotangent only (complete since the previous barrier): they run while the slower
+    // waves still write delta1
 #pragma unroll
     for (int J = 0; J < 4; ++J) wgrad_tile(gW1[J], h1R, RS, wave * 32, d2R, RS, J * 32, lane);
+    wgrad_tile(gW2, h2R, RS, wave * 32, wR, 36, 0, lane);
+    __syncthreads();   // delta1 complete
 #pragma unroll
     for (int t = 0; t < N_IT; ++t) wgrad_tile(gW0[t], xR, XS, 32 * t, d1R, RS, wave * 32, lane);
-    wgrad_tile(gW2, h2R, RS, wave * 32, wR, 36, 0, lane);
     {
       // bias gradients: column sums over the tile's samples (conflict-free: adjacent threads, adjacent columns)
       const float *img = (tid < HID) ? d2R : d1R;

@@ -188,9 +188,21 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
     // the Fisher cotangent's log_std_old (first 8 action columns): requested now, used in the element phase, so
     // that its HBM latency passes behind the JVP chain instead of between two barriers
     float lso0 = 0.0f;
-    if constexpr (MODE == MODE_FVP) {
+    float e_act0 = 0.0f, e_mu0 = 0.0f, e_logp = 0.0f, e_adv = 0.0f, e_cadv = 0.0f;   // same for the loss terms
+    {
       const int er0 = row0 + (tid & 31), a0 = tid >> 5;
-      if (a0 < d.A && er0 < p.n) lso0 = p.ls_old[(size_t)er0 * d.A + a0];
+      if (er0 < p.n) {
+        if constexpr (MODE != MODE_FVP) {
+          e_logp = p.logp_old[er0];
+          e_adv = p.adv[er0];
+          e_cadv = p.cadv[er0];
+        }
+        if (a0 < d.A) {
+          if constexpr (MODE != MODE_GRAD) lso0 = p.ls_old[(size_t)er0 * d.A + a0];
+          if constexpr (MODE != MODE_FVP) e_act0 = p.act[(size_t)er0 * d.A + a0];
+          if constexpr (MODE == MODE_EVAL) e_mu0 = p.mu_old[(size_t)er0 * d.A + a0];
+        }
+      }
     }
     f32x16 acc[1][1];
     if (cached) {
@@ -317,7 +329,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
           if (valid) {
             const float ls = p.w.ls[a];
             const float sd = expf(ls) + 1e-8f;
-            const float z = (p.act[(size_t)er * d.A + a] - m) / sd;
+            const float z = (((it == 0) ? e_act0 : p.act[(size_t)er * d.A + a]) - m) / sd;
             z_[it] = z;
             term = -0.5f * (z * z + 2.0f * ls + 1.8378770664093453f);   // gaussian_likelihood :46-48
           }
@@ -329,8 +341,8 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
       __syncthreads();
       float logp = logp_part;
       for (int a = 0; a < d.A; ++a) logp += wR[eb * 36 + a];
-      const float ratio = valid ? expf(logp - p.logp_old[er]) : 0.0f;        // cpo_policy.py:522
-      const float adv = valid ? p.adv[er] : 0.0f, cadv = valid ? p.cadv[er] : 0.0f;
+      const float ratio = valid ? expf(logp - e_logp) : 0.0f;                // cpo_policy.py:522
+      const float adv = e_adv, cadv = e_cadv;                                // (zero past the batch end)
       if (tid < 32 && valid) {
         s_n += 1.0;
         s_ra += (double)(ratio * adv);
@@ -345,8 +357,8 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
           if constexpr (MODE == MODE_EVAL) {
             if (valid) {
               // gaussian_kl(mu, log_std, mu_old, log_std_old), ac_network.py:50-55
-              const float ls = p.w.ls[a], lso = p.ls_old[(size_t)er * d.A + a];
-              const float dm = p.mu_old[(size_t)er * d.A + a] - mu_[it];
+              const float ls = p.w.ls[a], lso = (it == 0) ? lso0 : p.ls_old[(size_t)er * d.A + a];
+              const float dm = ((it == 0) ? e_mu0 : p.mu_old[(size_t)er * d.A + a]) - mu_[it];
               const float pre = 0.5f * ((dm * dm + expf(2.0f * ls)) / (expf(2.0f * lso) + 1e-8f) - 1.0f) + lso - ls;
               s_kl += (double)pre;
             }

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libcmbpo_hip.so")
 
 ACT_SWISH, ACT_TANH = 0, 1
 HEAD_PROB, HEAD_DETMEAN, HEAD_GAUSS_PI = 0, 1, 2
+LOSS_DEFAULT, LOSS_NLL = 0, 1      # cmbpo_trainer_set_loss
 TASK_DEFAULT, TASK_HCS, TASK_ANTSAFE = 0, 1, 2
 
 # models/statics.py:56-69 -- task name -> rule id
@@ -121,6 +122,7 @@ SIGNATURES.update({
 SIGNATURES.update({
     "cmbpo_trainer_create": (_i, [C.POINTER(_p), _p, _i, C.c_float, _p]),
     "cmbpo_trainer_destroy": (None, [_p]),
+    "cmbpo_trainer_set_loss": (_i, [_p, _i]),
     "cmbpo_trainer_set_weights": (_i, [_p] * 8),
     "cmbpo_trainer_get_weights": (_i, [_p] * 8),
     "cmbpo_trainer_reset_optimizer": (_i, [_p, _p]),

@@ -37,8 +37,9 @@ def _paths(model_dir, name, timestep):
 
 
 def save_ensemble(model_dir, name, timestep, weights, biases, activation, decays, probabilistic, scaler_in=None,
-                  scaler_out=None):
-    """weights[l]: [E, in, out]; biases[l]: [E, 1, out]; scaler_*: (mu[1, d], var[1, d]) or None."""
+                  scaler_out=None, logvar_bounds=None):
+    """weights[l]: [E, in, out]; biases[l]: [E, 1, out]; scaler_*: (mu[1, d], var[1, d]) or None; logvar_bounds:
+    (max_logvar[1, d], min_logvar[1, d]) of an 'NLL' model -- the last two optvars (pe.py:208-209) -- or None."""
     nns, mat = _paths(model_dir, name, timestep)
     n = len(weights)
     with open(nns, "w+") as f:
@@ -57,6 +58,10 @@ def save_ensemble(model_dir, name, timestep, weights, biases, activation, decays
         var_vals[str(k)] = np.asarray(w, np.float32)
         var_vals[str(k + 1)] = np.asarray(b, np.float32).reshape(w.shape[0], 1, w.shape[2])
         k += 2
+    if logvar_bounds is not None:
+        for a in logvar_bounds:
+            var_vals[str(k)] = np.asarray(a, np.float32).reshape(1, -1)
+            k += 1
     savemat(mat, var_vals)
     return nns, mat
 
@@ -86,7 +91,14 @@ def load_ensemble(model_dir, name, timestep=None, use_scaler_in=False, use_scale
         w = w.reshape(E, i, -1)
         weights.append(w)
         biases.append(b.reshape(E, 1, w.shape[2]))
+    bounds = None
+    if str(k) in d and str(k + 1) in d and str(k + 2) not in d:
+        # an 'NLL' model: max_logvar, min_logvar [1, out_dim] close the optvars (pe.py:208-209)
+        bounds = (take(), take())
+        width = weights[-1].shape[2]
+        if any(a.size not in (width, width // 2) for a in bounds):
+            raise ValueError("%s: trailing variables are not max / min_logvar of this structure" % mat)
     if str(k) in d:
-        raise ValueError("%s holds more variables than %s describes (scaler flags wrong, or an NLL model with "
-                         "max/min_logvar)" % (mat, nns))
-    return dict(layers=layers, weights=weights, biases=biases, scaler_in=sc_in, scaler_out=sc_out)
+        raise ValueError("%s holds more variables than %s describes (scaler flags wrong?)" % (mat, nns))
+    return dict(layers=layers, weights=weights, biases=biases, scaler_in=sc_in, scaler_out=sc_out,
+                logvar_bounds=bounds)

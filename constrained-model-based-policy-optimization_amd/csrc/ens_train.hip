@@ -141,9 +141,12 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdArgs p)
     // MSE (pe.py:911-919): total_e = mean 0.5 (o - t)^2.
     // The two sums behind `ratio` come from the forward's per-tile statistics, added here in tile order by every
     // workgroup (same order everywhere: reproducible).
+    // NLL (pe.py:840-919, inc_var_loss = True; prob == 2): total_e = mean 0.5 exp(-lv) (m - t)^2 + mean 0.5 lv; no
+    // coupling between members.  (Its max_logvar / min_logvar variables only carry a constant regulariser gradient
+    // and never enter the network, pe.py:198-209,263,789-838: they are host-side bookkeeping, pens.PE.)
     __shared__ double s_tot[2][kThreads / 64];
     float ratio = 0.0f;
-    if (p.prob) {
+    if (p.prob == 1) {
       double tm = 0.0, tv = 0.0;
       for (int w = tid; w < p.n_items; w += kThreads) {
         tm += p.loss_part[(size_t)w * 3];
@@ -176,6 +179,9 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdArgs p)
           const float diff = orow[dd] - t;
           if (!p.prob) {
             v = diff * inv_bd;
+          } else if (p.prob == 2) {
+            const float iv = expf(-orow[p.D + dd]);
+            v = (k < p.D) ? iv * diff * inv_bd : (0.5f - 0.5f * iv * diff * diff) * inv_bd;
           } else if (k < p.D) {
             v = 2.0f * diff * inv_bd;
           } else {
@@ -988,6 +994,7 @@ __global__ __launch_bounds__(kThreads) void adam_all_kernel(const AdamAllArgs p)
 struct cmbpo_trainer {
   cmbpo_mlp *m;
   int E, I, IP, H, O, OPk, D, prob, max_batch;
+  int nll;                       // probabilistic heads: 0 = 'MSPE' train loss, 1 = 'NLL' (cmbpo_trainer_set_loss)
   float lr, b1, b2, eps;
   float decay[3];
   long step;
@@ -1224,6 +1231,7 @@ extern "C" int cmbpo_trainer_create(cmbpo_trainer_t **out, cmbpo_mlp_t *m, int m
   t->E = m->ensemble; t->I = m->in_dim; t->IP = m->in_pad; t->H = m->hidden; t->O = m->o_width;
   t->OPk = (m->o_width + 7) / 8 * 8; t->D = m->out_dim; t->prob = m->head == CMBPO_HEAD_PROB;
   t->max_batch = max_batch;
+  t->nll = 0;
   t->lr = lr; t->b1 = 0.9f; t->b2 = 0.999f; t->eps = 1e-8f;
   for (int l = 0; l < 3; ++l) t->decay[l] = (float)decays[l];
   t->step = 0;
@@ -1370,6 +1378,14 @@ extern "C" int cmbpo_trainer_set_moments(cmbpo_trainer_t *t, int which, const fl
   return CMBPO_OK;
 }
 
+extern "C" int cmbpo_trainer_set_loss(cmbpo_trainer_t *t, int loss) {
+  CMBPO_REQUIRE(t != nullptr, "cmbpo_trainer_set_loss: handle is NULL");
+  CMBPO_REQUIRE(loss == CMBPO_LOSS_DEFAULT || loss == CMBPO_LOSS_NLL, "cmbpo_trainer_set_loss: unknown loss %d", loss);
+  CMBPO_REQUIRE(loss == CMBPO_LOSS_DEFAULT || t->prob, "cmbpo_trainer_set_loss: 'NLL' needs a probabilistic (HEAD_PROB) ensemble");
+  t->nll = loss == CMBPO_LOSS_NLL;
+  return CMBPO_OK;
+}
+
 extern "C" int cmbpo_trainer_reset_optimizer(cmbpo_trainer_t *t, void *stream) {
   CMBPO_REQUIRE(t != nullptr, "cmbpo_trainer_reset_optimizer: handle is NULL");
   hipStream_t s = (hipStream_t)stream;
@@ -1443,7 +1459,7 @@ extern "C" int cmbpo_trainer_step(cmbpo_trainer_t *t, const float *d_inputs, int
   b.B = batch; b.OPk = t->OPk;
   {
     cmbpo_mlp *m = t->m;
-    b.fuse = 1; b.prob = t->prob; b.O = t->O; b.D = t->D; b.n_items = E * cmbpo_ceil_div(batch, 32);
+    b.fuse = 1; b.prob = t->prob ? (t->nll ? 2 : 1) : 0; b.O = t->O; b.D = t->D; b.n_items = E * cmbpo_ceil_div(batch, 32);
     b.o = t->o; b.targets = d_targets; b.idx = d_idx; b.idx_stride = idx_stride;
     b.out_mu = m->has_out_scaler ? m->d_blob + m->off_out_mu : nullptr;
     b.out_sig = m->has_out_scaler ? m->d_blob + m->off_out_var : nullptr;

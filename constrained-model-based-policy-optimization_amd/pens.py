@@ -132,13 +132,15 @@ class EnsembleMLP:
 class EnsembleTrainer:
     """Owner of one ``cmbpo_trainer_t``: master weights, Adam moments and the activations of one step."""
 
-    def __init__(self, mlp, max_batch, lr, decays):
+    def __init__(self, mlp, max_batch, lr, decays, loss=None):
         self.mlp, self.max_batch = mlp, int(max_batch)
         self._h = C.c_void_p()
         dec = (C.c_double * 3)(*[float(d) for d in decays])
         with torch.cuda.device(mlp.device):
             _lib.check(_lib.lib().cmbpo_trainer_create(C.byref(self._h), mlp.handle, self.max_batch, float(lr), dec),
                        "cmbpo_trainer_create")
+            if loss == "NLL":     # 'MSPE' / 'MSE' are the handle's defaults for its head
+                _lib.check(_lib.lib().cmbpo_trainer_set_loss(self._h, _lib.LOSS_NLL), "cmbpo_trainer_set_loss")
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -337,7 +339,7 @@ class PE(TrainControl):
 
     def __init__(self, in_dim, out_dim, name="BNN", hidden_dims=(512, 512), num_networks=7,
                  num_elites=5, loss="MSPE", activation="swish", use_scaler_in=False,
-                 use_scaler_out=False, device=None, lr=1e-3, decay=1e-4, **_unused):
+                 use_scaler_out=False, device=None, lr=1e-3, decay=1e-4, max_logvar=.5, min_logvar=-6, **_unused):
         hidden_dims = tuple(int(h) for h in hidden_dims)
         if len(hidden_dims) != 2 or hidden_dims[0] != hidden_dims[1]:
             raise ValueError("the HIP path supports two equal hidden layers (all shipped configs: "
@@ -363,6 +365,13 @@ class PE(TrainControl):
         self.decays = (decay / 4.0, decay / 2.0, decay)
         self._trainer = None
         self._weights_on_device = False     # True once a train step has moved the masters past mlp._keep
+        # 'NLL' models own two more optimised variables (pe.py:198-209).  They never enter the network
+        # (_compile_outputs, pe.py:789-838); their only gradient is the constant +-0.01 of the regulariser (pe.py:263),
+        # so their value is a function of the number of optimiser steps -- kept here for checkpoint interchange.
+        self._lv_base = None
+        if self.loss_type == "NLL":
+            one = np.ones((1, self._out_dim), np.float32)
+            self._lv_base, self._lv_steps0 = (one * np.float32(max_logvar), one * np.float32(min_logvar)), 0
 
     # -- reference properties (pe.py:405-435) ---------------------------------
     @property
@@ -475,6 +484,35 @@ class PE(TrainControl):
         """pe.py:405-411: re-draw the layer variables (the optimizer state is NOT reset there either)."""
         self.init_weights()
 
+    # -- max_logvar / min_logvar of 'NLL' models ---------------------------------------------------------------------
+    @staticmethod
+    def _const_grad_adam_drift(c, n, lr, b1=0.9, b2=0.999, eps=1e-8):
+        """Total displacement of a variable after n tf.train.AdamOptimizer steps under the constant gradient c:
+        m_t = c (1 - b1^t), v_t = c^2 (1 - b2^t), lr_t = lr sqrt(1 - b2^t) / (1 - b1^t)."""
+        if n <= 0:
+            return 0.0
+        t = np.arange(1, int(n) + 1, dtype=np.float64)
+        root = np.sqrt(1.0 - b2 ** t)
+        return float(np.sum(lr * c * root / (abs(c) * root + eps)))
+
+    def _logvar_bounds(self):
+        if self._lv_base is None:
+            return None
+        n = (self._trainer.steps_done if self._trainer is not None else 0) - self._lv_steps0
+        hi = self._lv_base[0] - np.float32(self._const_grad_adam_drift(0.01, n, self.lr))
+        lo = self._lv_base[1] - np.float32(self._const_grad_adam_drift(-0.01, n, self.lr))
+        return hi.astype(np.float32), lo.astype(np.float32)
+
+    @property
+    def max_logvar(self):
+        b = self._logvar_bounds()
+        return None if b is None else b[0]
+
+    @property
+    def min_logvar(self):
+        b = self._logvar_bounds()
+        return None if b is None else b[1]
+
     # -- checkpoints (pe.py:736-783; file format in checkpoint.py) ----------------
     def save(self, savedir, timestep):
         """Writes <name>_<timestep>.nns / .mat exactly as the reference does (structure + nonoptvars + optvars)."""
@@ -484,7 +522,8 @@ class PE(TrainControl):
         sc = lambda s: (s.cached_mu, s.cached_var)
         return checkpoint.save_ensemble(
             savedir, self.name, timestep, ws, bs, self.activation, self.decays, self.is_probabilistic,
-            sc(self.scaler_in) if self.use_scaler_in else None, sc(self.scaler_out) if self.use_scaler_out else None)
+            sc(self.scaler_in) if self.use_scaler_in else None, sc(self.scaler_out) if self.use_scaler_out else None,
+            logvar_bounds=self._logvar_bounds())
 
     def load(self, model_dir, timestep=None):
         """Loads <name>[_<timestep>].nns / .mat (the reference reads <name>.nns / <name>.mat, pe.py:355-361,766-783)."""
@@ -497,7 +536,14 @@ class PE(TrainControl):
                              % (got, ck["weights"][0].shape[0], want, self.num_nets))
         if ck["layers"][0]["activation"] != self.activation:
             raise ValueError("checkpoint activation %r != %r" % (ck["layers"][0]["activation"], self.activation))
+        if (ck["logvar_bounds"] is None) != (self._lv_base is None):
+            raise ValueError("checkpoint %s max_logvar / min_logvar, this ensemble's loss is %r"
+                             % ("holds" if ck["logvar_bounds"] is not None else "lacks", self.loss_type))
         self.set_weights(ck["weights"], ck["biases"], ck["scaler_in"], ck["scaler_out"])
+        if self._lv_base is not None:
+            hi, lo = ck["logvar_bounds"]
+            self._lv_base = (hi.reshape(1, -1).astype(np.float32), lo.reshape(1, -1).astype(np.float32))
+            self._lv_steps0 = self._trainer.steps_done if self._trainer is not None else 0
         return ck
 
     # -- prediction --------------------------------------------------------------
@@ -567,7 +613,7 @@ class PE(TrainControl):
         # a larger batch than any seen before re-creates the step buffers; weights and Adam state move over
         old = self._trainer
         state = None if old is None else (old.get_moments(0), old.get_moments(1), old.steps_done)
-        self._trainer = EnsembleTrainer(self.mlp, max(int(batch_size), 32), self.lr, self.decays)
+        self._trainer = EnsembleTrainer(self.mlp, max(int(batch_size), 32), self.lr, self.decays, self.loss_type)
         self._trainer.set_weights(ws, bs)
         if state is not None:
             (mw, mb), (vw, vb), steps = state
@@ -585,8 +631,8 @@ class PE(TrainControl):
         return np.sort(losses)[:self.num_elites].mean()
 
     def _check_train_args(self, kwargs):
-        if self.loss_type not in ("MSPE", "MSE"):
-            raise NotImplementedError("HIP training covers the losses the shipped configs use ('MSPE', 'MSE'); got %r"
+        if self.loss_type not in ("MSPE", "MSE", "NLL"):
+            raise NotImplementedError("HIP training covers 'MSPE', 'MSE' (the shipped configs) and 'NLL'; got %r"
                                       % (self.loss_type,))
         if kwargs.get("weights") is not None or kwargs.get("old_pred") is not None:
             raise NotImplementedError("weighted / clipped losses (vf_clipping) are off in every shipped config")
@@ -671,4 +717,5 @@ def build_PE(in_dim, out_dim, name="BNN", hidden_dims=(200, 200, 200), num_netwo
         raise NotImplementedError("clipped value losses (vf_clipping) are off in every shipped config")
     return PE(in_dim, out_dim, name=name, hidden_dims=hidden_dims, num_networks=num_networks,
               num_elites=num_elites, loss=loss, activation=activation, use_scaler_in=use_scaler_in,
-              use_scaler_out=use_scaler_out, device=device, lr=lr, decay=decay)
+              use_scaler_out=use_scaler_out, device=device, lr=lr, decay=decay, max_logvar=max_logvar,
+              min_logvar=min_logvar)

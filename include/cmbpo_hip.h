@@ -388,6 +388,13 @@ typedef struct cmbpo_trainer cmbpo_trainer_t;
 int cmbpo_trainer_create(cmbpo_trainer_t **out, cmbpo_mlp_t *m, int max_batch, float lr,
                          const double *decays);
 void cmbpo_trainer_destroy(cmbpo_trainer_t *t);
+/* Train loss (PE.finalize, models/pens/pe.py:240-300).  DEFAULT: 'MSPE' (_mspe_loss, :921-973) for probabilistic
+ * heads, 'MSE' (_nll_loss(inc_var_loss=False), :840-919) for deterministic ones -- what the shipped configs use.
+ * NLL: _nll_loss(inc_var_loss=True) = mean 0.5 exp(-log_var)(mean - t)^2 + mean 0.5 log_var, probabilistic heads
+ * only (the class default of PE, pe.py:65).  `self.loss` (cmbpo_trainer_losses) is the same for all of them. */
+#define CMBPO_LOSS_DEFAULT 0
+#define CMBPO_LOSS_NLL 1
+int cmbpo_trainer_set_loss(cmbpo_trainer_t *t, int loss);
 /* Host weights in the reference variable layout (W[E][in][out], b[E][out]) -> masters and the
  * handle's packed images; the Adam state is untouched (the reference keeps it across train()
  * calls, pe.py:318).  get_weights copies the masters back (checkpointing, models/pens/pe.py:736-764). */

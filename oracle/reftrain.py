@@ -6,6 +6,9 @@ TF half ("parity unpinned": TensorFlow 1.14 cannot run here, the reference has n
     ``tf.matmul`` per member, ``models/pens/fc.py:89-95``);
   * MSPE train loss (:921-973): per-member mean squared error + variance-fit term with the stop-gradient ratio
     0.05 * mean(mse) / mean((var - mse)^2) taken over ALL members, + 0.05 * mean(log_var^2);
+  * NLL train loss (:840-919 with inc_var_loss=True; the class default of PE): per-member mean 0.5 exp(-lv)(m - t)^2
+    + mean 0.5 lv; its max_logvar / min_logvar variables never enter the network (:789-838) and only drift under the
+    constant gradient of their regulariser (:263) -- :func:`logvar_bounds`;
   * MSE train loss for deterministic ensembles (critics; ``_nll_loss(inc_var_loss=False)``, :840-919);
   * weight decay ``decay_l * tf.nn.l2_loss(W_l)`` per layer (``models/pens/fc.py:167-168``, ``pe_factory.py:50-56``);
   * ``self.loss`` used for holdout / elite ranking = per-member 0.5 * mean((mean - target)^2) (:264, :840-919);
@@ -64,6 +67,30 @@ def mse_losses(o, t_scaled):
     return (0.5 * (o - t_scaled) ** 2).mean(dim=-1).mean(dim=-1)
 
 
+def nll_losses(o, t_scaled):
+    """_nll_loss(inc_var_loss=True), pe.py:840-919 (no clipping, no weights) -> per-member total_losses [E]."""
+    out = o.shape[-1] // 2
+    mean, log_var = o[..., :out], o[..., out:]
+    inv_var = torch.exp(-log_var)
+    var_losses = (0.5 * log_var).mean(dim=-1).mean(dim=-1)
+    mse_losses_ = (0.5 * inv_var * (mean - t_scaled) ** 2).mean(dim=-1).mean(dim=-1)
+    return mse_losses_ + var_losses
+
+
+def logvar_bounds(steps, lr, max0, min0, b1=0.9, b2=0.999, eps=1e-8):
+    """max_logvar / min_logvar of an 'NLL' model after `steps` Adam steps (pe.py:198-209,263): they never enter the
+    network (_compile_outputs, :789-838), their gradient is the constant +-0.01 of the regulariser, so their
+    trajectory is that of tf.train.AdamOptimizer under a constant gradient."""
+    hi, lo = np.array(max0, np.float64).copy(), np.array(min0, np.float64).copy()
+    for c, var in ((0.01, hi), (-0.01, lo)):
+        m = v = 0.0
+        for t in range(1, int(steps) + 1):
+            m += (c - m) * (1 - b1)
+            v += (c * c - v) * (1 - b2)
+            var -= lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * m / (np.sqrt(v) + eps)
+    return hi.astype(F32), lo.astype(F32)
+
+
 def holdout_losses(o, t_scaled, probabilistic):
     mean = o[..., : o.shape[-1] // 2] if probabilistic else o
     return mse_losses(mean, t_scaled)
@@ -73,7 +100,7 @@ def train_loss(ws, bs, x, t, loss_type, decays, scaler_in=None, scaler_out=None)
     """The scalar the optimizer minimises: sum of per-member losses + decays (pe.py:252-274)."""
     o = forward_raw(x, ws, bs, scaler_in)
     ts = scale_targets(t, scaler_out)
-    per_member = mspe_losses(o, ts) if loss_type == "MSPE" else mse_losses(o, ts)
+    per_member = {"MSPE": mspe_losses, "NLL": nll_losses, "MSE": mse_losses}[loss_type](o, ts)
     loss = per_member.sum()
     for w, d in zip(ws, decays):
         loss = loss + d * 0.5 * (w ** 2).sum()
@@ -133,7 +160,7 @@ class EnsembleTrainer:
         with torch.no_grad():
             o = forward_raw(torch.as_tensor(x, dtype=self.dtype), self.ws, self.bs, self.scaler_in)
             ts = scale_targets(torch.as_tensor(t, dtype=self.dtype), self.scaler_out)
-            return holdout_losses(o, ts, self.loss_type == "MSPE").numpy()
+            return holdout_losses(o, ts, self.loss_type in ("MSPE", "NLL")).numpy()
 
 
 # --------------------------------------------------------------------------------------------------------

@@ -69,6 +69,8 @@ CASES = [  # E, I, H, D, loss, batch
     (2, 100, 128, 64, "MSPE", 40),   # 128 raw outputs (4 output tiles), wide input
     (3, 23, 512, 11, "MSPE", 70),    # HalfCheetah-like dynamics (odd output width 22)
     (2, 100, 128, 2, "MSE", 40),     # input too wide for the fused kernel: the general path on a deterministic head
+    (7, 37, 512, 30, "NLL", 256),    # the class-default loss of PE on the dynamics shapes
+    (3, 11, 128, 4, "NLL", 100),
 ]
 
 
@@ -101,7 +103,7 @@ def test_first_step_gradients_and_losses(hip_lib, E, I, H, D, loss, batch):
     assert tr.steps_done == 1
 
 
-@pytest.mark.parametrize("E,I,H,D,loss,batch", CASES[:3])
+@pytest.mark.parametrize("E,I,H,D,loss,batch", CASES[:3] + CASES[-1:])
 def test_several_adam_steps_track_oracle(hip_lib, E, I, H, D, loss, batch):
     _need_gpu()
     rng, pe, ref, x, t, ws, bs = _make(E, I, H, D, loss, 500, seed=7 + E)
@@ -124,7 +126,7 @@ def test_several_adam_steps_track_oracle(hip_lib, E, I, H, D, loss, batch):
     # the packed images the prediction kernels read follow the masters
     pe._weights_on_device = True
     xs = x[:50]
-    if loss == "MSPE":
+    if loss in ("MSPE", "NLL"):
         from oracle import refcpu
         mean, var = pe.predict_ensemble(xs)
         sc_in = (pe.scaler_in.cached_mu, pe.scaler_in.cached_var)
@@ -172,7 +174,7 @@ class _OracleOps:
         return self.ref.losses(np.tile(self.x[rows][None], (E, 1, 1)), np.tile(self.t[rows][None], (E, 1, 1)))
 
 
-@pytest.mark.parametrize("loss,D", [("MSPE", 3), ("MSE", 1)])
+@pytest.mark.parametrize("loss,D", [("MSPE", 3), ("MSE", 1), ("NLL", 3)])
 def test_pe_train_follows_oracle_loop(hip_lib, loss, D):
     """PE.train end to end (same numpy RandomState on both sides): epochs, gradient updates, scaler moments,
     holdout losses and the elite ranking."""
@@ -309,3 +311,43 @@ def test_policy_checkpoint_round_trip(hip_lib, tmp_path):
     a, b = pol.get_action_outs(obs, eps=eps), pol2.get_action_outs(obs, eps=eps)
     for k in ("pi", "logp_pi", "v", "vc"):
         np.testing.assert_array_equal(a[k], b[k])
+
+
+def test_nll_checkpoint_carries_logvar_bounds(hip_lib, tmp_path):
+    """An 'NLL' model saves max_logvar / min_logvar as its last two variables (pe.py:208-209,760-764); they drift with
+    the optimiser steps as tf.train.AdamOptimizer moves them under the regulariser's constant gradient."""
+    _need_gpu()
+    from scipy.io import loadmat
+    from cmbpo_amd.pens import PE
+    E, I, H, D, batch = 3, 11, 128, 4, 64
+    rng, pe, ref, x, t, ws, bs = _make(E, I, H, D, "NLL", 300, seed=5)
+    np.testing.assert_array_equal(pe.max_logvar, np.full((1, D), 0.5, np.float32))
+    np.testing.assert_array_equal(pe.min_logvar, np.full((1, D), -6.0, np.float32))
+    tr = pe._ensure_trainer(batch)
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    for _ in range(5):
+        idx = torch.from_numpy(rng.randint(0, x.shape[0], size=(E, batch)).astype(np.int32)).cuda()
+        tr.step(xd, td, idx.data_ptr(), batch, batch)
+    pe._weights_on_device = True
+    hi, lo = reftrain.logvar_bounds(5, pe.lr, np.full((1, D), 0.5), np.full((1, D), -6.0))
+    np.testing.assert_allclose(pe.max_logvar, hi, rtol=1e-6)
+    np.testing.assert_allclose(pe.min_logvar, lo, rtol=1e-6)
+    nns, mat = pe.save(str(tmp_path), 7)
+    d = loadmat(mat)
+    n_vars = len([k for k in d if k.isdigit()])
+    assert n_vars == 4 + 6 + 2                      # two scalers, three layers, the two bounds
+    np.testing.assert_allclose(d[str(n_vars - 2)], hi, rtol=1e-6)
+    np.testing.assert_allclose(d[str(n_vars - 1)], lo, rtol=1e-6)
+    pe2 = PE(I, D, name="T", hidden_dims=(H, H), num_networks=E, num_elites=1, loss="NLL", use_scaler_in=True,
+             use_scaler_out=True, device="cuda:0")
+    pe2.load(str(tmp_path), 7)
+    np.testing.assert_allclose(pe2.max_logvar, hi, rtol=1e-6)
+    gw, gb = pe.get_weights()
+    gw2, gb2 = pe2.get_weights()
+    for a, b in zip(gw + gb, gw2 + gb2):
+        np.testing.assert_array_equal(a, b)
+    # an MSPE model refuses the NLL file (its variable list is two entries shorter) and vice versa
+    pe3 = PE(I, D, name="T", hidden_dims=(H, H), num_networks=E, num_elites=1, loss="MSPE", use_scaler_in=True,
+             use_scaler_out=True, device="cuda:0")
+    with pytest.raises(ValueError):
+        pe3.load(str(tmp_path), 7)

@@ -186,3 +186,39 @@ def test_weight_decay_and_member_sum_in_train_loss():
     assert loss_e.shape == (E,)
     base = loss_e - 0.05 * (lv ** 2).mean()
     assert float((loss_e.sum() - base.sum())) == pytest.approx(E * 0.05 * float((lv ** 2).mean()), rel=1e-12)
+
+
+def test_nll_deltas_closed_form_and_bounds_drift():
+    """'NLL' (the class default of PE): d(train_loss)/d(raw output) as the HIP kernel computes it == autograd of the
+    restated loss; max_logvar / min_logvar follow Adam under their constant regulariser gradient, and the product's
+    closed form of that drift == the step-by-step rule."""
+    rng = np.random.default_rng(3)
+    E, B, D = 3, 13, 5
+    o = torch.tensor(rng.standard_normal((E, B, 2 * D)), dtype=torch.float64, requires_grad=True)
+    t = torch.tensor(rng.standard_normal((E, B, D)), dtype=torch.float64)
+    reftrain.nll_losses(o, t).sum().backward()
+    od = o.detach()
+    mean, lv = od[..., :D], od[..., D:]
+    iv = torch.exp(-lv)
+    np.testing.assert_allclose(o.grad[..., :D].numpy(), (iv * (mean - t) / (B * D)).numpy(), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(o.grad[..., D:].numpy(), ((0.5 - 0.5 * iv * (mean - t) ** 2) / (B * D)).numpy(),
+                               rtol=1e-12, atol=1e-15)
+    # the value is the Gaussian negative log-likelihood up to the constant 0.5 log(2 pi)
+    nll = -torch.distributions.Normal(mean, torch.exp(0.5 * lv)).log_prob(t).mean(dim=-1).mean(dim=-1)
+    np.testing.assert_allclose((reftrain.nll_losses(od, t) + 0.5 * np.log(2 * np.pi)).numpy(), nll.numpy(), rtol=1e-12)
+    # bounds: AdamTF on the two variables with gradient +-0.01 == logvar_bounds == the product's closed form
+    hi0, lo0 = np.full((1, D), 0.5), np.full((1, D), -6.0)
+    opt = reftrain.AdamTF([torch.tensor(hi0), torch.tensor(lo0)], lr=1e-3)
+    ps = [torch.tensor(hi0), torch.tensor(lo0)]
+    for _ in range(37):
+        ps = opt.step(ps, [torch.full((1, D), 0.01, dtype=torch.float64), torch.full((1, D), -0.01, dtype=torch.float64)])
+    hi, lo = reftrain.logvar_bounds(37, 1e-3, hi0, lo0)
+    np.testing.assert_allclose(hi, ps[0].numpy(), rtol=1e-6)
+    np.testing.assert_allclose(lo, ps[1].numpy(), rtol=1e-6)
+    sys.path.insert(0, os.path.dirname(HERE)) if os.path.dirname(HERE) not in sys.path else None
+    import cmbpo_amd  # noqa: F401
+    from cmbpo_amd.pens import PE
+    drift = PE._const_grad_adam_drift
+    np.testing.assert_allclose(0.5 - drift(0.01, 37, 1e-3), float(ps[0][0, 0]), rtol=1e-9)
+    np.testing.assert_allclose(-6.0 - drift(-0.01, 37, 1e-3), float(ps[1][0, 0]), rtol=1e-9)
+    assert drift(0.01, 0, 1e-3) == 0.0

@@ -51,9 +51,11 @@ def test_handles_reject_bad_shapes_and_unloaded_use(hip_lib):
         tr.step(x, t, None, 0, 65)
     with pytest.raises(CmbpoHipError, match="in_dim|target_dim"):
         tr.step(torch.zeros(4, 7, device="cuda"), t, None, 0, 4)
-    nll = PE(8, 2, hidden_dims=(128, 128), num_networks=3, num_elites=2, loss="NLL", device="cuda:0")
+    ce = PE(8, 2, hidden_dims=(128, 128), num_networks=3, num_elites=2, loss="CE", device="cuda:0")
     with pytest.raises(NotImplementedError):
-        nll.train(np.zeros((10, 8), np.float32), np.zeros((10, 2), np.float32))
+        ce.train(np.zeros((10, 8), np.float32), np.zeros((10, 2), np.float32), max_epochs=1)
+    with pytest.raises(CmbpoHipError, match="NLL"):               # 'NLL' needs a probabilistic head
+        _lib.check(lib.cmbpo_trainer_set_loss(ce._ensure_trainer(32)._h, _lib.LOSS_NLL), "cmbpo_trainer_set_loss")
     del EnsembleMLP
 
 

@@ -248,6 +248,23 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
   }
 #endif
 
+  // biases of the item's first member: requested before the input tile, so that their latency passes together with
+  // the row-index -> row-gather chain below instead of after it
+  constexpr int kMaxB = (2 * HID + 128 + kThreads - 1) / kThreads;
+  float bias_tmp[kMaxB];
+  auto fetch_bias = [&](int e) {
+    const int o_pad = p.o_tiles * 32;
+#pragma unroll
+    for (int u = 0; u < kMaxB; ++u) {
+      const int i = tid + u * kThreads;
+      bias_tmp[u] = 0.0f;
+      if (i < 2 * HID + o_pad)
+        bias_tmp[u] = (i < HID) ? p.b0[(size_t)e * HID + i]
+                                : (i < 2 * HID) ? p.b1[(size_t)e * HID + (i - HID)] : p.b2[(size_t)e * o_pad + (i - 2 * HID)];
+    }
+  };
+  fetch_bias(chunk * p.e_chunk);
+
   // ---- stage the (scaled) input tile: xT[k][b], k = [obs | act] ------------
   // 8 threads per branch row; every thread issues all of its (independent) global loads before it
   // touches LDS, so the prologue pays the memory latency once instead of once per element.
@@ -308,20 +325,11 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
     STAMP(1);
     if (e > e_begin) __syncthreads();   // previous member's epilogue still reads bias_l / red (= hbuf)
     {
-      constexpr int kMaxB = (2 * HID + 128 + kThreads - 1) / kThreads;
-      float tmp[kMaxB];
+      if (e > e_begin) fetch_bias(e);
 #pragma unroll
       for (int u = 0; u < kMaxB; ++u) {
         const int i = tid + u * kThreads;
-        tmp[u] = 0.0f;
-        if (i < 2 * HID + o_pad)
-          tmp[u] = (i < HID) ? p.b0[(size_t)e * HID + i]
-                             : (i < 2 * HID) ? p.b1[(size_t)e * HID + (i - HID)] : p.b2[(size_t)e * o_pad + (i - 2 * HID)];
-      }
-#pragma unroll
-      for (int u = 0; u < kMaxB; ++u) {
-        const int i = tid + u * kThreads;
-        if (i < 2 * HID + o_pad) bias_l[i] = tmp[u];
+        if (i < 2 * HID + o_pad) bias_l[i] = bias_tmp[u];
       }
     }
     __syncthreads();   // x tile (first member) and this member's biases are in LDS

@@ -596,6 +596,7 @@ extern "C" int cmbpo_mlp_create(cmbpo_mlp_t **out, int ensemble, int in_dim, int
 extern "C" void cmbpo_mlp_destroy(cmbpo_mlp_t *m) {
   if (!m) return;
   if (m->d_blob) (void)hipFree(m->d_blob);
+  if (m->d_split) (void)hipFree(m->d_split);
   delete m;
 }
 
@@ -642,6 +643,7 @@ extern "C" int cmbpo_mlp_load(cmbpo_mlp_t *m, const float *h_w0, const float *h_
   }
   if (h_log_std) memcpy(hb + m->off_log_std, h_log_std, m->out_dim * sizeof(float));
   // h_blob stays alive in the handle until the next load, so the async copy is safe.
+  ++m->pack_version;
   CMBPO_HIP_CHECK(hipMemcpyAsync(m->d_blob, hb, m->blob_floats * sizeof(float),
                                  hipMemcpyHostToDevice, (hipStream_t)stream));
   m->loaded = true;
@@ -701,6 +703,7 @@ int launch_one(MlpKernelArgs &a, int tiles, int chunks, size_t lds, hipStream_t 
 }
 
 int g_block_rows = 32;  // 32 (2 workgroups / CU) or 64 (1 workgroup / CU)
+int g_split_path = getenv("CMBPO_ENS_SPLIT") ? atoi(getenv("CMBPO_ENS_SPLIT")) : 0;   // 1: ens_split.hip for the 512-wide PROB forward
 int g_stagger = 10;     // x s_sleep(127) (~8k cycles each) for the second dispatch batch
 int g_lds_pad = 0;      // diagnostic: extra dynamic LDS bytes (forces one workgroup per CU)
 
@@ -731,6 +734,8 @@ int launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s, int head_override 
   a.o_width = m->o_width; a.o_tiles = m->o_tiles; a.out_dim = m->out_dim;
   if (a.n_rows <= 0) return CMBPO_OK;
 
+  if (head == CMBPO_HEAD_PROB && H == 512 && m->act == CMBPO_ACT_SWISH && m->o_tiles == 2 && m->in_pad <= 64 && g_split_path)
+    return cmbpo_internal_launch_split(m, a, s);
   const int BT = (H == 512 && g_block_rows == 64 && head != CMBPO_HEAD_TRAIN) ? 2 : 1;
   const int BB = 32 * BT;
   const int tiles = cmbpo_ceil_div(a.n_rows, BB);

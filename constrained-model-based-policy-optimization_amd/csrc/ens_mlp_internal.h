@@ -56,8 +56,15 @@ struct cmbpo_mlp {
   size_t off_wp0, off_wp1, off_wp2, off_b0, off_b1, off_b2;
   size_t off_in_mu, off_in_var, off_out_mu, off_out_var, off_out_lsig2, off_log_std;   // *_var hold sigma
   std::vector<float> h_blob;
+  // split-bf16 forward (ens_split.hip): three bf16 images of the packed weights, rebuilt when the packs change
+  void *d_split = nullptr;
+  unsigned long pack_version = 0, split_version = ~0ul;
+  size_t sp_off[3] = {0, 0, 0}, sp_stride[3] = {0, 0, 0};   // 16-B units
 };
 
 // fills the weight / scaler pointers of `a` from the handle and launches the kernel matching (hidden, act, head);
 // head_override >= 0 replaces the handle's head (HEAD_TRAIN on a PROB / DETMEAN handle).
 int cmbpo_internal_launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s, int head_override);
+// HEAD_PROB, 512-wide, swish: the same forward on the bf16 matrix cores (fp32 products as six bf16 MFMAs); `a` filled
+// as for cmbpo_internal_launch_mlp
+int cmbpo_internal_launch_split(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s);

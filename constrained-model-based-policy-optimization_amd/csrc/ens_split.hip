@@ -1,0 +1,370 @@
+// Ensemble forward (HEAD_PROB, 512-wide, swish) with the fp32 GEMMs carried by the bf16 matrix cores.
+//
+// Same function as ens_mlp_kernel<512, *, swish, prob> (models/pens/pe.py:688-697,789-838, fc.py:74-95): one item =
+// 64 rows of one member through  x -> swish(x W0 + b0) -> swish(. W1 + b1) -> . W2 + b2 -> (mean, var).
+// An fp32 product a.b is computed as sum_{i+j<=4} a_i b_j with a = a1 + a2 + a3, a_i the successive bf16 roundings of
+// the remainder (3 x 8 = 24 mantissa bits): six v_mfma_f32_32x32x16_bf16 with fp32 accumulation, every partial
+// product exact, the dropped terms <= 2^-24 |ab|.  Measured (tools/split_bf16_probe.hip): error 6.2e-7 of sum|a_k b_k|
+// at K = 512 (the fp32 MFMA chain: 7.6e-7), 2.08x the fp32-MFMA rate.
+//
+// Layout: weights are split once per weight change into three bf16 images in MFMA fragment order
+//   [n-tile 32][k-slab 16][image 3][lane 64][8 bf16]   (lane (r, h) holds W[n = r][k = 16 s + 8 h + j]),
+// streamed from L2 (1.9 MB per member); 64 rows per item halve that stream per row against 32 (L2 -> CU bandwidth is
+// the next bound after the matrix pipe).  Activations stay fp32 in LDS in the row layout [row][516] (conflict-free
+// 16-B reads: 516 / 4 odd) and are split into their three images when a wave reads its B fragment -- three images of a
+// 512-wide layer for 64 rows do not fit LDS, and the split (converts / subtracts) issues in the shadow of the MFMAs.
+// 4 waves, one per SIMD: wave w owns hidden n-tiles 4w .. 4w+3 for both 32-row halves (48 MFMAs per 16 split values per
+// lane: the split issues in the MFMA gaps of the same wave).  The output layer takes its B operand straight from the
+// accumulators (an accumulator tile's rows are the next product's k index, so the wave's own h2 slice is split once,
+// in registers, with the matching permutation baked into the W2 images), K split over the waves, partial outputs
+// reduced through LDS -- the structure of ens_mlp_kernel's output layer.
+#include "common.h"
+#include "ens_mlp_internal.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int kThreadsS = 256;
+constexpr int HIDS = 512;
+constexpr int ROWS = 64;          // rows per item
+constexpr int HS = HIDS + 4;      // row stride of the activation image
+constexpr int RED_LDS = ROWS + 1;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Split3 {
+  bf16x8 p1, p2, p3;
+};
+
+__device__ __forceinline__ Split3 split8(const f32x4 lo, const f32x4 hi) {
+  Split3 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float a = j < 4 ? lo[j] : hi[j - 4];
+    const __bf16 q1 = (__bf16)a;
+    const float r1 = a - (float)q1;      // exact
+    const __bf16 q2 = (__bf16)r1;
+    const float r2 = r1 - (float)q2;     // exact
+    o.p1[j] = q1; o.p2[j] = q2; o.p3[j] = (__bf16)r2;
+  }
+  return o;
+}
+
+// six-term product, smallest terms first
+__device__ __forceinline__ void mfma6(f32x16 &acc, const Split3 &a, const Split3 &b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p3, b.p1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b.p3, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, b.p2, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, b.p1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b.p2, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b.p1, acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float swishf(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+// ---- fp32 pack [n-tile][k-group 8][lane][4] -> three bf16 images [n-tile][k-slab 16][image][lane][8] ---------------
+// perm == 0: lane (r, h), element j of slab s holds W[n = 32 tile + r][k = 16 s + 8 h + j].
+// perm == 1 (output layer, B operand = accumulator registers): slab S = 8 w + 2 t + half covers the hidden units
+// wave w holds in registers 8 half .. 8 half + 7 of its tile t: k = 128 w + 32 t + (i & 3) + 8 (i >> 2) + 4 h, i = 8 half + j.
+__global__ void split_pack_kernel(const float *src, size_t src_stride, int kg, bf16x8 *dst, size_t dst_stride, int n_tiles,
+                                  int slabs, int members, int perm) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per = (long)n_tiles * slabs * 64;
+  if (idx >= per * members) return;
+  const int e = (int)(idx / per);
+  const int rem = (int)(idx - (long)e * per);
+  const int lane = rem & 63, s = (rem >> 6) % slabs, tile = (rem >> 6) / slabs;
+  const int r = lane & 31, h = lane >> 5;
+  const float *sp = src + (size_t)e * src_stride;
+  f32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int k = 16 * s + 8 * h + j;
+    if (perm) {
+      const int i = 8 * (s & 1) + j;
+      k = 128 * (s >> 3) + 32 * ((s >> 1) & 3) + (i & 3) + 8 * (i >> 2) + 4 * h;
+    }
+    float v = 0.0f;
+    if ((k >> 3) < kg) v = sp[(((size_t)tile * kg + (k >> 3)) * 64 + ((k >> 2) & 1) * 32 + r) * 4 + (k & 3)];
+    if (j < 4) lo[j] = v; else hi[j - 4] = v;
+  }
+  const Split3 sp3 = split8(lo, hi);
+  bf16x8 *d = dst + (size_t)e * dst_stride + ((size_t)tile * slabs + s) * 3 * 64 + lane;
+  d[0] = sp3.p1; d[64] = sp3.p2; d[128] = sp3.p3;
+}
+
+struct SplitArgs {
+  MlpKernelArgs m;
+  const bf16x8 *sp0, *sp1, *sp2;
+  size_t sp0_stride, sp1_stride, sp2_stride;   // per member, in 16-B units
+  int slabs0;                                  // k-slabs of the input layer (in_pad rounded up to 16)
+};
+
+constexpr int NTS = 4;   // hidden n-tiles per wave
+
+struct RawB {
+  f32x4 x0, x1, y0, y1;
+};
+
+// one hidden layer: acc[t][bt] += W[n-tiles 4w + t] . B[rows 32 bt ..] over `slabs` k-slabs; B from the fp32 row image.
+// Software pipeline, one slab deep, pinned with scheduling barriers (left alone the compiler sinks the weight loads
+// into the iteration that consumes them and every slab waits out an L2 round trip): while the 48 MFMAs of slab s issue,
+// the weight fragments of slab s + 1 are in flight, the B rows of slab s + 1 are split and those of s + 2 are read.
+__device__ __forceinline__ void split_layer(f32x16 (&acc)[NTS][2], const bf16x8 *wp, int slabs, const float *img, int stride,
+                                            int wave, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const bf16x8 *wa = wp + (size_t)(NTS * wave) * slabs * 3 * 64 + lane;
+  const size_t tstep = (size_t)slabs * 3 * 64;
+  const float *b0 = img + (size_t)r * stride + 8 * h, *b1 = b0 + (size_t)32 * stride;
+  auto load_a = [&](Split3 (&a)[NTS], int s) {
+#pragma unroll
+    for (int t = 0; t < NTS; ++t) {
+      const bf16x8 *q = wa + t * tstep + (size_t)s * 192;
+      a[t].p1 = q[0]; a[t].p2 = q[64]; a[t].p3 = q[128];
+    }
+  };
+  auto read_b = [&](int s) {
+    RawB v;
+    v.x0 = *reinterpret_cast<const f32x4 *>(b0 + 16 * s); v.x1 = *reinterpret_cast<const f32x4 *>(b0 + 16 * s + 4);
+    v.y0 = *reinterpret_cast<const f32x4 *>(b1 + 16 * s); v.y1 = *reinterpret_cast<const f32x4 *>(b1 + 16 * s + 4);
+    return v;
+  };
+  Split3 a_cur[NTS], a_nxt[NTS], bx_cur, by_cur, bx_nxt, by_nxt;
+  load_a(a_cur, 0);
+  RawB raw_nxt = read_b(0), raw_nn;
+  bx_cur = split8(raw_nxt.x0, raw_nxt.x1); by_cur = split8(raw_nxt.y0, raw_nxt.y1);
+  raw_nxt = read_b(slabs > 1 ? 1 : 0);
+  for (int s = 0; s < slabs; ++s) {
+    const int s1 = (s + 1 < slabs) ? s + 1 : s, s2 = (s + 2 < slabs) ? s + 2 : s1;
+    load_a(a_nxt, s1);
+    raw_nn = read_b(s2);
+    __builtin_amdgcn_sched_barrier(0);
+    bx_nxt = split8(raw_nxt.x0, raw_nxt.x1); by_nxt = split8(raw_nxt.y0, raw_nxt.y1);
+#pragma unroll
+    for (int t = 0; t < NTS; ++t) {
+      mfma6(acc[t][0], a_cur[t], bx_cur);
+      mfma6(acc[t][1], a_cur[t], by_cur);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NTS; ++t) a_cur[t] = a_nxt[t];
+    bx_cur = bx_nxt; by_cur = by_nxt; raw_nxt = raw_nn;
+  }
+}
+
+__global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a) {
+  const MlpKernelArgs &p = a.m;
+  extern __shared__ f32x4 smem4[];
+  float *hbuf = reinterpret_cast<float *>(smem4);          // [ROWS][HS]; later the partial outputs [4][64][RED_LDS]
+  const int kpad0 = a.slabs0 * 16, XS = kpad0 + 4;
+  float *xs = hbuf + ROWS * HS;                            // [ROWS][XS] scaled input, zero padded
+  float *bias_l = xs + ROWS * XS;                          // [HID | HID | 64]
+  float *oconst = bias_l + 2 * HIDS + 64;                  // [sig | 2 log sig | mu] x out_dim
+  int *rows = reinterpret_cast<int *>(oconst + 3 * p.out_dim);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int n_rows = p.n_rows_dev ? *p.n_rows_dev : p.n_rows;
+  const int item = blockIdx.x;
+  const int e = item / p.tiles;
+  const int row0 = (item - e * p.tiles) * ROWS;
+  if (row0 >= n_rows) return;
+
+  // ---- biases, output scaler constants, input tile ------------------------------------------------------------
+  const int o_pad = p.o_tiles * 32;   // 64
+  for (int i = tid; i < 2 * HIDS + o_pad; i += kThreadsS)
+    bias_l[i] = (i < HIDS) ? p.b0[(size_t)e * HIDS + i]
+                           : (i < 2 * HIDS) ? p.b1[(size_t)e * HIDS + (i - HIDS)] : p.b2[(size_t)e * o_pad + (i - 2 * HIDS)];
+  if (tid < p.out_dim) {
+    oconst[tid] = p.out_mu ? p.out_sig[tid] : 1.0f;
+    oconst[p.out_dim + tid] = p.out_mu ? p.out_lsig2[tid] : 0.0f;
+    oconst[2 * p.out_dim + tid] = p.out_mu ? p.out_mu[tid] : 0.0f;
+  }
+  {
+    const int c = tid & 3, b = tid >> 2;
+    int rr = row0 + b;
+    rr = (rr < n_rows) ? (p.row_idx ? p.row_idx[rr] : rr) : -1;
+    if (c == 0) rows[b] = rr;
+    for (int k = c; k < kpad0; k += 4) {
+      float x = 0.0f;
+      if (k < p.in_dim && rr >= 0) {
+        x = (k < p.obs_dim) ? p.obs[(size_t)rr * p.obs_dim + k] : p.act[(size_t)rr * p.act_dim + (k - p.obs_dim)];
+        if (p.in_mu) x = (x - p.in_mu[k]) / p.in_sig[k];   // TensorStandardScaler.transform, models/pens/utils.py:156
+      }
+      xs[b * XS + k] = x;
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc[NTS][2];
+  auto init_bias = [&](const float *bias) {
+#pragma unroll
+    for (int t = 0; t < NTS; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + (NTS * wave + t) * 32 + 8 * q + 4 * h);
+#pragma unroll
+        for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[t][bt][4 * q + s] = bv[s];
+      }
+  };
+  auto swish_acc = [&]() {
+#pragma unroll
+    for (int t = 0; t < NTS; ++t)
+#pragma unroll
+      for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][bt][i] = swishf(acc[t][bt][i]);
+  };
+
+  // ---- layer 0: in -> 512 -----------------------------------------------------------------------------------
+  init_bias(bias_l);
+  split_layer(acc, a.sp0 + (size_t)e * a.sp0_stride, a.slabs0, xs, XS, wave, lane);
+  swish_acc();
+#pragma unroll
+  for (int t = 0; t < NTS; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int bt = 0; bt < 2; ++bt) {
+        f32x4 v;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = acc[t][bt][4 * q + s];
+        *reinterpret_cast<f32x4 *>(hbuf + (size_t)(32 * bt + r) * HS + (NTS * wave + t) * 32 + 8 * q + 4 * h) = v;
+      }
+  __syncthreads();
+  // ---- layer 1: 512 -> 512 ----------------------------------------------------------------------------------
+  init_bias(bias_l + HIDS);
+  split_layer(acc, a.sp1 + (size_t)e * a.sp1_stride, HIDS / 16, hbuf, HS, wave, lane);
+  swish_acc();
+  // ---- layer 2: 512 -> 2 out (64 padded), K split over the waves, B operand = this wave's h2 registers ----------
+  f32x16 o[2][2];
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[t2][bt][i] = 0.0f;
+  {
+    const bf16x8 *w2 = a.sp2 + (size_t)e * a.sp2_stride + lane;
+    constexpr int S2 = HIDS / 16;   // slabs per output tile
+#pragma unroll
+    for (int t = 0; t < NTS; ++t)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int S = 8 * wave + 2 * t + half;
+        Split3 wa[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          const bf16x8 *q = w2 + ((size_t)t2 * S2 + S) * 192;
+          wa[t2].p1 = q[0]; wa[t2].p2 = q[64]; wa[t2].p3 = q[128];
+        }
+#pragma unroll
+        for (int bt = 0; bt < 2; ++bt) {
+          f32x4 lo, hi;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { lo[j] = acc[t][bt][8 * half + j]; hi[j] = acc[t][bt][8 * half + 4 + j]; }
+          const Split3 b = split8(lo, hi);
+          mfma6(o[0][bt], wa[0], b);
+          mfma6(o[1][bt], wa[1], b);
+        }
+      }
+  }
+  __syncthreads();         // every wave has finished reading h1: hbuf becomes the partial-output image
+  float *red = hbuf;       // [wave][n 64][RED_LDS]
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = t2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        red[(wave * 64 + n) * RED_LDS + 32 * bt + r] = o[t2][bt][i];
+      }
+  __syncthreads();
+  // ---- head: mean = sig * o + mu ; var = exp(2 log sig + o')   (models/pens/pe.py:815-835) -----------------------
+  auto reduced = [&](int b, int n) -> float {
+    float v = red[(0 * 64 + n) * RED_LDS + b];
+    v += red[(1 * 64 + n) * RED_LDS + b];
+    v += red[(2 * 64 + n) * RED_LDS + b];
+    v += red[(3 * 64 + n) * RED_LDS + b];
+    return v + bias_l[2 * HIDS + n];
+  };
+  const int out = p.out_dim;
+  const float inv_out = 1.0f / (float)out;
+  for (int i = tid; i < ROWS * out; i += kThreadsS) {
+    const int b = (int)(((float)i + 0.5f) * inv_out);
+    const int n = i - b * out;
+    const int rr = rows[b];
+    if (rr < 0) continue;
+    const float m = oconst[n] * reduced(b, n) + oconst[2 * out + n];
+    const float lv = oconst[out + n] + reduced(b, out + n);
+    const size_t oo = ((size_t)e * p.ld_rows + rr) * out + n;
+    p.out0[oo] = m;
+    p.out1[oo] = __expf(lv);
+  }
+}
+
+}  // namespace
+
+// ---- host side -------------------------------------------------------------------------------------------------
+// (re)builds the three bf16 images from the handle's fp32 packs when they changed since the last build
+static int ensure_split(cmbpo_mlp *m, hipStream_t s) {
+  const int H = m->hidden, E = m->ensemble;
+  const int slabs[3] = {(m->in_pad + 15) / 16, H / 16, H / 16};
+  const int tiles[3] = {H / 32, H / 32, m->o_tiles};
+  if (m->d_split == nullptr) {
+    size_t off = 0;
+    for (int l = 0; l < 3; ++l) {
+      m->sp_stride[l] = (size_t)tiles[l] * slabs[l] * 3 * 64;
+      m->sp_off[l] = off;
+      off += m->sp_stride[l] * E;
+    }
+    if (hipMalloc(&m->d_split, off * 16) != hipSuccess) {
+      (void)hipGetLastError();
+      m->d_split = nullptr;
+      cmbpo_set_error("ens_split: hipMalloc of the bf16 weight images failed");
+      return CMBPO_ENOMEM;
+    }
+    m->split_version = ~0ul;
+  }
+  if (m->split_version == m->pack_version) return CMBPO_OK;
+  const size_t src_off[3] = {m->off_wp0, m->off_wp1, m->off_wp2};
+  const int kg[3] = {m->in_pad / 8, H / 8, H / 8};
+  for (int l = 0; l < 3; ++l) {
+    const size_t src_stride = (size_t)tiles[l] * kg[l] * 256;
+    const long total = (long)tiles[l] * slabs[l] * 64 * E;
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, m->d_blob + src_off[l],
+                       src_stride, kg[l], reinterpret_cast<bf16x8 *>(m->d_split) + m->sp_off[l], m->sp_stride[l], tiles[l],
+                       slabs[l], E, l == 2 ? 1 : 0);
+  }
+  CMBPO_HIP_CHECK(hipGetLastError());
+  m->split_version = m->pack_version;
+  return CMBPO_OK;
+}
+
+int cmbpo_internal_launch_split(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
+  if (int rc = ensure_split(m, s)) return rc;
+  SplitArgs k{};
+  k.m = a;
+  const bf16x8 *base = reinterpret_cast<const bf16x8 *>(m->d_split);
+  k.sp0 = base + m->sp_off[0]; k.sp1 = base + m->sp_off[1]; k.sp2 = base + m->sp_off[2];
+  k.sp0_stride = m->sp_stride[0]; k.sp1_stride = m->sp_stride[1]; k.sp2_stride = m->sp_stride[2];
+  k.slabs0 = (m->in_pad + 15) / 16;
+  const int tiles = cmbpo_ceil_div(a.n_rows, ROWS);
+  k.m.tiles = tiles;
+  k.m.n_items = tiles * m->ensemble;
+  const size_t lds = ((size_t)ROWS * HS + (size_t)ROWS * (k.slabs0 * 16 + 4) + 2 * HIDS + 64 + 3 * m->out_dim + ROWS) * sizeof(float);
+  CMBPO_REQUIRE(lds <= 160 * 1024, "ens_split: LDS budget exceeded (%zu B)", lds);
+  static size_t attr_bytes = 0;
+  if (lds > attr_bytes) {
+    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ens_split_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_bytes = lds;
+  }
+  hipLaunchKernelGGL(ens_split_kernel, dim3(k.m.n_items), dim3(kThreadsS), lds, s, k);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}

@@ -1105,6 +1105,7 @@ int launch_bwd(const BwdArgs &a, int tiles, int E, size_t lds, hipStream_t s) {
 // masters -> packs (apply == 0) or one Adam step (apply == 1)
 int launch_update(cmbpo_trainer *t, int apply, float lr_t, hipStream_t s) {
   cmbpo_mlp *m = t->m;
+  ++m->pack_version;   // the packed images change: derived images (ens_split.hip) are stale
   const int E = t->E, H = t->H;
   const int Ks[3] = {t->I, H, H}, Ns[3] = {H, H, t->O};
   float *fwd[3] = {m->d_blob + m->off_wp0, m->d_blob + m->off_wp1, m->d_blob + m->off_wp2};

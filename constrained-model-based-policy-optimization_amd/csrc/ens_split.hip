@@ -130,27 +130,34 @@ __device__ __forceinline__ void split_layer(f32x16 (&acc)[NTS][2], const bf16x8 
     v.y0 = *reinterpret_cast<const f32x4 *>(b1 + 16 * s); v.y1 = *reinterpret_cast<const f32x4 *>(b1 + 16 * s + 4);
     return v;
   };
-  Split3 a_cur[NTS], a_nxt[NTS], bx_cur, by_cur, bx_nxt, by_nxt;
-  load_a(a_cur, 0);
-  RawB raw_nxt = read_b(0), raw_nn;
-  bx_cur = split8(raw_nxt.x0, raw_nxt.x1); by_cur = split8(raw_nxt.y0, raw_nxt.y1);
-  raw_nxt = read_b(slabs > 1 ? 1 : 0);
-  for (int s = 0; s < slabs; ++s) {
+  // two register sets in ping-pong (a copy "current = next" per slab is 32 moves in front of the MFMAs)
+  Split3 A[2][NTS], BX[2], BY[2];
+  RawB R[2];
+  load_a(A[0], 0);
+  R[0] = read_b(0);
+  BX[0] = split8(R[0].x0, R[0].x1); BY[0] = split8(R[0].y0, R[0].y1);
+  R[1] = read_b(slabs > 1 ? 1 : 0);
+  auto step = [&](int s, Split3 (&a_use)[NTS], Split3 (&a_ld)[NTS], const Split3 &bx_use, const Split3 &by_use, Split3 &bx_mk,
+                  Split3 &by_mk, const RawB &raw_use, RawB &raw_ld) {
     const int s1 = (s + 1 < slabs) ? s + 1 : s, s2 = (s + 2 < slabs) ? s + 2 : s1;
-    load_a(a_nxt, s1);
-    raw_nn = read_b(s2);
+    load_a(a_ld, s1);
+    const RawB nn = read_b(s2);
     __builtin_amdgcn_sched_barrier(0);
-    bx_nxt = split8(raw_nxt.x0, raw_nxt.x1); by_nxt = split8(raw_nxt.y0, raw_nxt.y1);
+    bx_mk = split8(raw_use.x0, raw_use.x1); by_mk = split8(raw_use.y0, raw_use.y1);
 #pragma unroll
     for (int t = 0; t < NTS; ++t) {
-      mfma6(acc[t][0], a_cur[t], bx_cur);
-      mfma6(acc[t][1], a_cur[t], by_cur);
+      mfma6(acc[t][0], a_use[t], bx_use);
+      mfma6(acc[t][1], a_use[t], by_use);
     }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < NTS; ++t) a_cur[t] = a_nxt[t];
-    bx_cur = bx_nxt; by_cur = by_nxt; raw_nxt = raw_nn;
+    raw_ld = nn;
+  };
+  int s = 0;
+  for (; s + 1 < slabs; s += 2) {
+    step(s, A[0], A[1], BX[0], BY[0], BX[1], BY[1], R[1], R[0]);
+    step(s + 1, A[1], A[0], BX[1], BY[1], BX[0], BY[0], R[0], R[1]);
   }
+  if (s < slabs) step(s, A[0], A[1], BX[0], BY[0], BX[1], BY[1], R[1], R[0]);
 }
 
 __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a) {
@@ -166,35 +173,63 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int n_rows = p.n_rows_dev ? *p.n_rows_dev : p.n_rows;
-  const int item = blockIdx.x;
-  const int e = item / p.tiles;
-  const int row0 = (item - e * p.tiles) * ROWS;
-  if (row0 >= n_rows) return;
-
-  // ---- biases, output scaler constants, input tile ------------------------------------------------------------
   const int o_pad = p.o_tiles * 32;   // 64
-  for (int i = tid; i < 2 * HIDS + o_pad; i += kThreadsS)
-    bias_l[i] = (i < HIDS) ? p.b0[(size_t)e * HIDS + i]
-                           : (i < 2 * HIDS) ? p.b1[(size_t)e * HIDS + (i - HIDS)] : p.b2[(size_t)e * o_pad + (i - 2 * HIDS)];
-  if (tid < p.out_dim) {
+  if (tid < p.out_dim) {   // output scaler constants, once per workgroup (models/pens/utils.py:167,187)
     oconst[tid] = p.out_mu ? p.out_sig[tid] : 1.0f;
     oconst[p.out_dim + tid] = p.out_mu ? p.out_lsig2[tid] : 0.0f;
     oconst[2 * p.out_dim + tid] = p.out_mu ? p.out_mu[tid] : 0.0f;
   }
-  {
-    const int c = tid & 3, b = tid >> 2;
-    int rr = row0 + b;
-    rr = (rr < n_rows) ? (p.row_idx ? p.row_idx[rr] : rr) : -1;
-    if (c == 0) rows[b] = rr;
-    for (int k = c; k < kpad0; k += 4) {
+  // Persistent workgroups (one per CU: 150 KB of LDS): with a single workgroup per CU nothing else covers an item's
+  // prologue, so the NEXT item's input rows are gathered into registers behind the 512 x 512 layer of the current one
+  // (row index first, then the dependent row gather), and the dispatcher's turnaround between items disappears.
+  constexpr int XPRE = 16;            // >= kpad0 / 4 (in_pad <= 64)
+  const int xc = tid & 3, xb = tid >> 2;
+  float xpre[XPRE];
+  int rr_pre = -1;
+  auto item_rows = [&](int it, int &e_out, int &row0_out) {
+    e_out = it / p.tiles;
+    row0_out = (it - e_out * p.tiles) * ROWS;
+  };
+  auto fetch_row = [&](int it) {
+    int e2, r2;
+    item_rows(it, e2, r2);
+    const int rr = r2 + xb;
+    rr_pre = (it < p.n_items && rr < n_rows) ? (p.row_idx ? p.row_idx[rr] : rr) : -1;
+  };
+  auto fetch_x = [&]() {
+#pragma unroll
+    for (int u = 0; u < XPRE; ++u) {
+      const int k = xc + 4 * u;
       float x = 0.0f;
-      if (k < p.in_dim && rr >= 0) {
-        x = (k < p.obs_dim) ? p.obs[(size_t)rr * p.obs_dim + k] : p.act[(size_t)rr * p.act_dim + (k - p.obs_dim)];
+      if (k < p.in_dim && rr_pre >= 0) {
+        x = (k < p.obs_dim) ? p.obs[(size_t)rr_pre * p.obs_dim + k] : p.act[(size_t)rr_pre * p.act_dim + (k - p.obs_dim)];
         if (p.in_mu) x = (x - p.in_mu[k]) / p.in_sig[k];   // TensorStandardScaler.transform, models/pens/utils.py:156
       }
-      xs[b * XS + k] = x;
+      xpre[u] = x;
     }
+  };
+  fetch_row(blockIdx.x);
+  fetch_x();
+
+  for (int item = blockIdx.x; item < p.n_items; item += gridDim.x) {
+  int e, row0;
+  item_rows(item, e, row0);
+  if (row0 >= n_rows) {    // (uniform) nothing alive in this tile; keep the prefetch chain going
+    fetch_row(item + gridDim.x);
+    fetch_x();
+    continue;
   }
+  // ---- biases of this member, input tile from the prefetch registers ------------------------------------------------
+  for (int i = tid; i < 2 * HIDS + o_pad; i += kThreadsS)
+    bias_l[i] = (i < HIDS) ? p.b0[(size_t)e * HIDS + i]
+                           : (i < 2 * HIDS) ? p.b1[(size_t)e * HIDS + (i - HIDS)] : p.b2[(size_t)e * o_pad + (i - 2 * HIDS)];
+  if (xc == 0) rows[xb] = rr_pre;
+#pragma unroll
+  for (int u = 0; u < XPRE; ++u) {
+    const int k = xc + 4 * u;
+    if (k < kpad0) xs[xb * XS + k] = xpre[u];
+  }
+  fetch_row(item + gridDim.x);     // the next item's row index: lands during layer 0
   __syncthreads();
 
   f32x16 acc[NTS][2];
@@ -235,6 +270,7 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
         *reinterpret_cast<f32x4 *>(hbuf + (size_t)(32 * bt + r) * HS + (NTS * wave + t) * 32 + 8 * q + 4 * h) = v;
       }
   __syncthreads();
+  fetch_x();               // the next item's rows: in flight behind layer 1
   // ---- layer 1: 512 -> 512 ----------------------------------------------------------------------------------
   init_bias(bias_l + HIDS);
   split_layer(acc, a.sp1 + (size_t)e * a.sp1_stride, HIDS / 16, hbuf, HS, wave, lane);
@@ -298,13 +334,16 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
     const int b = (int)(((float)i + 0.5f) * inv_out);
     const int n = i - b * out;
     const int rr = rows[b];
-    if (rr < 0) continue;
     const float m = oconst[n] * reduced(b, n) + oconst[2 * out + n];
     const float lv = oconst[out + n] + reduced(b, out + n);
-    const size_t oo = ((size_t)e * p.ld_rows + rr) * out + n;
-    p.out0[oo] = m;
-    p.out1[oo] = __expf(lv);
+    if (rr >= 0) {
+      const size_t oo = ((size_t)e * p.ld_rows + rr) * out + n;
+      p.out0[oo] = m;
+      p.out1[oo] = __expf(lv);
+    }
   }
+  __syncthreads();         // the next item overwrites rows / bias / the images
+  }  // persistent item loop
 }
 
 }  // namespace
@@ -364,7 +403,15 @@ int cmbpo_internal_launch_split(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_bytes = lds;
   }
-  hipLaunchKernelGGL(ens_split_kernel, dim3(k.m.n_items), dim3(kThreadsS), lds, s, k);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  const int grid = k.m.n_items < n_cu ? k.m.n_items : n_cu;
+  hipLaunchKernelGGL(ens_split_kernel, dim3(grid), dim3(kThreadsS), lds, s, k);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }

@@ -27,6 +27,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense
+SPLIT_TERMS = 6                 # bf16 MFMAs per float32 product on the split path (csrc/ens_split.hip)
 MAXROLL = 35
 
 
@@ -281,11 +283,20 @@ def main():
     avg_ms = float(np.mean(k_ms)) if k_ms else float("nan")
     achieved = flop_per_row * float(np.mean(k_rows)) / (avg_ms * 1e-3) / 1e12 if k_ms else float("nan")
 
+    # which matrix path ran: fp32 MFMAs, or float32 products carried by six bf16 MFMAs each (same float32 results
+    # within rounding, same parity tests).  The roofline of the latter is the bf16 dense peak divided by the six
+    # MFMAs a float32 product costs; `achieved` stays the ALGORITHMIC float32 flops per second either way.
+    from cmbpo_amd import _lib
+    split = H == 512 and _lib.lib().cmbpo_get_ens_matrix_path() == 1
+    peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS if split else PEAK_FP32_MFMA_TFLOPS
+    kernel_name = "ens_split_kernel (6 x v_mfma_f32_32x32x16_bf16 per f32 product)" if split else "ens_mlp_kernel<512,1,swish,prob>"
+    pmc_file = "pmc_traffic_split.json" if split else "pmc_traffic.json"
+
     # HBM traffic of the dominant kernel: PMC counters collected offline (separate rocprofv3 --pmc passes, see
     # profiles/r01/pmc_traffic.json), scaled to this run's rows per launch
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01", pmc_file)) as f:
             pmc = json.load(f)
         if task == "AntSafe-v2" and k_rows:
             traffic = pmc["hbm_bytes_per_launch"] * float(np.mean(k_rows)) / pmc["rows_per_launch"]
@@ -304,17 +315,20 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if not split else "f32 (products as 6 bf16 MFMAs on exact 3-way bf16 splits, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": f"{task} imagined rollout: E={E} x ({D + A}->{H}->{H}->{2 * (D + 1)}) swish ensemble, 5 elites, "
                                    f"3+3 critics 128x128, tanh policy 128x128, B={B} branches/GPU, maxroll 35 "
                                    f"(34 steps), reset->sample*->finish_all_paths->get()",
                        "branches_per_gpu": B, "horizon": MAXROLL - 1, "task": task,
                        "samples_per_step": tot / args.steps},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel": "ens_mlp_kernel<512,1,swish,prob>", "avg_launch_ms": avg_ms,
-                         "launches": len(k_ms), "flop_per_branch_step": flop_per_row},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
+                         "kernel": kernel_name, "avg_launch_ms": avg_ms,
+                         "launches": len(k_ms), "flop_per_branch_step": flop_per_row,
+                         "peak_basis": ("bf16 dense 2500 TFLOP/s / 6 MFMAs per f32 product" if split
+                                        else "fp32 MFMA dense 157.3 TFLOP/s"),
+                         "vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS},
         }
         out["cpo_update"] = {"unit": "ms", "n_50k": n50, "ms_50k": upd_ms_50k, "n_full": n_full,
                              "ms_full": upd_ms_full, "optim_case": int(upd_info["OptimCase"]),

@@ -703,7 +703,7 @@ int launch_one(MlpKernelArgs &a, int tiles, int chunks, size_t lds, hipStream_t 
 }
 
 int g_block_rows = 32;  // 32 (2 workgroups / CU) or 64 (1 workgroup / CU)
-int g_split_path = getenv("CMBPO_ENS_SPLIT") ? atoi(getenv("CMBPO_ENS_SPLIT")) : 0;   // 1: ens_split.hip for the 512-wide PROB forward
+int g_split_path = getenv("CMBPO_ENS_SPLIT") ? (atoi(getenv("CMBPO_ENS_SPLIT")) != 0) : 1;   // 1: ens_split.hip for the 512-wide PROB forward
 int g_stagger = 10;     // x s_sleep(127) (~8k cycles each) for the second dispatch batch
 int g_lds_pad = 0;      // diagnostic: extra dynamic LDS bytes (forces one workgroup per CU)
 
@@ -771,6 +771,14 @@ int launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s, int head_override 
 int cmbpo_internal_launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s, int head_override) {
   return launch_mlp(m, a, s, head_override);
 }
+
+extern "C" int cmbpo_set_ens_matrix_path(int path) {
+  CMBPO_REQUIRE(path == CMBPO_ENS_FP32 || path == CMBPO_ENS_SPLIT_BF16, "cmbpo_set_ens_matrix_path: 0 (fp32 MFMA) or 1 (split bf16)");
+  g_split_path = path;
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_get_ens_matrix_path(void) { return g_split_path; }
 
 extern "C" int cmbpo_set_dispatch_mode(int mode) {
   CMBPO_REQUIRE(mode >= 0 && mode <= 2, "cmbpo_set_dispatch_mode: 0 (per-item), 1 (persistent static), 2 (persistent dynamic)");

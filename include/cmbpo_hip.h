@@ -61,6 +61,18 @@ int cmbpo_set_stagger(int sleeps);
  * (hardware dispatch), 1 = persistent workgroups with static striding, 2 = persistent with a device work
  * counter. */
 int cmbpo_set_dispatch_mode(int mode);
+/* Matrix path of the 512-wide probabilistic ensemble forward (cmbpo_ens_forward / cmbpo_rollout_step): same
+ * function, same float32 inputs / outputs, two ways to form the float32 products of its three GEMMs.
+ * CMBPO_ENS_FP32: v_mfma_f32_32x32x2f32.  CMBPO_ENS_SPLIT_BF16 (default): every operand is split exactly into
+ * three bf16 pieces (3 x 8 = 24 mantissa bits) and a.b = sum_{i+j<=4} a_i b_j runs as six
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- every partial product exact, dropped terms <= 2^-24 |ab|,
+ * measured error 6.2e-7 of sum|a_k b_k| at K = 512 against 7.6e-7 for the fp32 MFMA chain
+ * (tools/split_bf16_probe.hip) -- at about twice the matrix rate.  Both pass the same parity tests.  The
+ * environment variable CMBPO_ENS_SPLIT=0/1 sets the initial value.  Other shapes / heads always use fp32 MFMAs. */
+#define CMBPO_ENS_FP32 0
+#define CMBPO_ENS_SPLIT_BF16 1
+int cmbpo_set_ens_matrix_path(int path);
+int cmbpo_get_ens_matrix_path(void);
 
 /* ------------------------------------------------------------------------ *
  * Ensemble MLP handle: a 3-layer (in -> H -> H -> O) ensemble of E members.

@@ -18,3 +18,13 @@ def hip_lib():
     import cmbpo_amd  # noqa: F401
     from cmbpo_amd import _lib
     return _lib.lib()
+
+
+@pytest.fixture
+def ens_path(hip_lib, request):
+    """Selects the matrix path of the 512-wide ensemble forward for one test and restores the default afterwards."""
+    from cmbpo_amd import _lib
+    before = hip_lib.cmbpo_get_ens_matrix_path()
+    _lib.check(hip_lib.cmbpo_set_ens_matrix_path(request.param), "cmbpo_set_ens_matrix_path")
+    yield request.param
+    hip_lib.cmbpo_set_ens_matrix_path(before)

@@ -140,14 +140,26 @@ __device__ __forceinline__ void split_layer(f32x16 (&acc)[NTS][2], const bf16x8 
   auto step = [&](int s, Split3 (&a_use)[NTS], Split3 (&a_ld)[NTS], const Split3 &bx_use, const Split3 &by_use, Split3 &bx_mk,
                   Split3 &by_mk, const RawB &raw_use, RawB &raw_ld) {
     const int s1 = (s + 1 < slabs) ? s + 1 : s, s2 = (s + 2 < slabs) ? s + 2 : s1;
+    __builtin_amdgcn_sched_barrier(0);
     load_a(a_ld, s1);
     const RawB nn = read_b(s2);
-    __builtin_amdgcn_sched_barrier(0);
     bx_mk = split8(raw_use.x0, raw_use.x1); by_mk = split8(raw_use.y0, raw_use.y1);
 #pragma unroll
     for (int t = 0; t < NTS; ++t) {
       mfma6(acc[t][0], a_use[t], bx_use);
       mfma6(acc[t][1], a_use[t], by_use);
+    }
+    // A wave issues in order: whatever stands between two MFMAs in the instruction stream runs in the shadow of the
+    // first (its 32 cycles in the pipe, 8 of them holding the issue port), whatever stands in front of a run of MFMAs
+    // delays all of them.  So the slab's other work is dealt out one gap at a time: a weight-fragment load (~27 cycles
+    // of issue) every fourth gap, the four LDS reads in the first gaps, three of the split's VALU instructions in
+    // every other gap.
+#pragma unroll
+    for (int i = 0; i < 12 * NTS; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
+      if ((i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // 1 VMEM read
+      else __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                  // 3 VALU
+      if (i < 8 && (i & 1)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // 1 DS read
     }
     __builtin_amdgcn_sched_barrier(0);
     raw_ld = nn;

@@ -734,7 +734,7 @@ int launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s, int head_override 
   a.o_width = m->o_width; a.o_tiles = m->o_tiles; a.out_dim = m->out_dim;
   if (a.n_rows <= 0) return CMBPO_OK;
 
-  if (head == CMBPO_HEAD_PROB && H == 512 && m->act == CMBPO_ACT_SWISH && m->o_tiles == 2 && m->in_pad <= 64 && g_split_path)
+  if (head == CMBPO_HEAD_PROB && H == 512 && m->act == CMBPO_ACT_SWISH && m->o_tiles <= 4 && m->in_pad <= 64 && g_split_path)
     return cmbpo_internal_launch_split(m, a, s);
   const int BT = (H == 512 && g_block_rows == 64 && head != CMBPO_HEAD_TRAIN) ? 2 : 1;
   const int BB = 32 * BT;

@@ -172,6 +172,7 @@ __device__ __forceinline__ void split_layer(f32x16 (&acc)[NTS][2], const bf16x8 
   if (s < slabs) step(s, A[0], A[1], BX[0], BY[0], BX[1], BY[1], R[1], R[0]);
 }
 
+template <int OT>   // output n-tiles: 2 out_dim <= 32 OT
 __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a) {
   const MlpKernelArgs &p = a.m;
   extern __shared__ f32x4 smem4[];
@@ -179,13 +180,13 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
   const int kpad0 = a.slabs0 * 16, XS = kpad0 + 4;
   float *xs = hbuf + ROWS * HS;                            // [ROWS][XS] scaled input, zero padded
   float *bias_l = xs + ROWS * XS;                          // [HID | HID | 64]
-  float *oconst = bias_l + 2 * HIDS + 64;                  // [sig | 2 log sig | mu] x out_dim
+  float *oconst = bias_l + 2 * HIDS + OT * 32;             // [sig | 2 log sig | mu] x out_dim
   int *rows = reinterpret_cast<int *>(oconst + 3 * p.out_dim);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int n_rows = p.n_rows_dev ? *p.n_rows_dev : p.n_rows;
-  const int o_pad = p.o_tiles * 32;   // 64
+  constexpr int o_pad = OT * 32;
   if (tid < p.out_dim) {   // output scaler constants, once per workgroup (models/pens/utils.py:167,187)
     oconst[tid] = p.out_mu ? p.out_sig[tid] : 1.0f;
     oconst[p.out_dim + tid] = p.out_mu ? p.out_lsig2[tid] : 0.0f;
@@ -220,8 +221,23 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
       xpre[u] = x;
     }
   };
+  // this member's biases travel the same way (1088 floats: five registers per thread)
+  constexpr int BPRE = (2 * HIDS + o_pad + kThreadsS - 1) / kThreadsS;
+  float bpre[BPRE];
+  auto fetch_bias = [&](int it) {
+    const int e2 = (it < p.n_items) ? it / p.tiles : 0;
+#pragma unroll
+    for (int u = 0; u < BPRE; ++u) {
+      const int i = tid + u * kThreadsS;
+      bpre[u] = 0.0f;
+      if (i < 2 * HIDS + o_pad)
+        bpre[u] = (i < HIDS) ? p.b0[(size_t)e2 * HIDS + i]
+                             : (i < 2 * HIDS) ? p.b1[(size_t)e2 * HIDS + (i - HIDS)] : p.b2[(size_t)e2 * o_pad + (i - 2 * HIDS)];
+    }
+  };
   fetch_row(blockIdx.x);
   fetch_x();
+  fetch_bias(blockIdx.x);
 
   for (int item = blockIdx.x; item < p.n_items; item += gridDim.x) {
   int e, row0;
@@ -229,12 +245,15 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
   if (row0 >= n_rows) {    // (uniform) nothing alive in this tile; keep the prefetch chain going
     fetch_row(item + gridDim.x);
     fetch_x();
+    fetch_bias(item + gridDim.x);
     continue;
   }
   // ---- biases of this member, input tile from the prefetch registers ------------------------------------------------
-  for (int i = tid; i < 2 * HIDS + o_pad; i += kThreadsS)
-    bias_l[i] = (i < HIDS) ? p.b0[(size_t)e * HIDS + i]
-                           : (i < 2 * HIDS) ? p.b1[(size_t)e * HIDS + (i - HIDS)] : p.b2[(size_t)e * o_pad + (i - 2 * HIDS)];
+#pragma unroll
+  for (int u = 0; u < BPRE; ++u) {
+    const int i = tid + u * kThreadsS;
+    if (i < 2 * HIDS + o_pad) bias_l[i] = bpre[u];
+  }
   if (xc == 0) rows[xb] = rr_pre;
 #pragma unroll
   for (int u = 0; u < XPRE; ++u) {
@@ -282,15 +301,16 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
         *reinterpret_cast<f32x4 *>(hbuf + (size_t)(32 * bt + r) * HS + (NTS * wave + t) * 32 + 8 * q + 4 * h) = v;
       }
   __syncthreads();
-  fetch_x();               // the next item's rows: in flight behind layer 1
+  fetch_x();               // the next item's rows and biases: in flight behind layer 1
+  fetch_bias(item + gridDim.x);
   // ---- layer 1: 512 -> 512 ----------------------------------------------------------------------------------
   init_bias(bias_l + HIDS);
   split_layer(acc, a.sp1 + (size_t)e * a.sp1_stride, HIDS / 16, hbuf, HS, wave, lane);
   swish_acc();
   // ---- layer 2: 512 -> 2 out (64 padded), K split over the waves, B operand = this wave's h2 registers ----------
-  f32x16 o[2][2];
+  f32x16 o[OT][2];
 #pragma unroll
-  for (int t2 = 0; t2 < 2; ++t2)
+  for (int t2 = 0; t2 < OT; ++t2)
 #pragma unroll
     for (int bt = 0; bt < 2; ++bt)
 #pragma unroll
@@ -303,9 +323,9 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int S = 8 * wave + 2 * t + half;
-        Split3 wa[2];
+        Split3 wa[OT];
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
+        for (int t2 = 0; t2 < OT; ++t2) {
           const bf16x8 *q = w2 + ((size_t)t2 * S2 + S) * 192;
           wa[t2].p1 = q[0]; wa[t2].p2 = q[64]; wa[t2].p3 = q[128];
         }
@@ -315,43 +335,49 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
 #pragma unroll
           for (int j = 0; j < 4; ++j) { lo[j] = acc[t][bt][8 * half + j]; hi[j] = acc[t][bt][8 * half + 4 + j]; }
           const Split3 b = split8(lo, hi);
-          mfma6(o[0][bt], wa[0], b);
-          mfma6(o[1][bt], wa[1], b);
+#pragma unroll
+          for (int t2 = 0; t2 < OT; ++t2) mfma6(o[t2][bt], wa[t2], b);
         }
       }
   }
   __syncthreads();         // every wave has finished reading h1: hbuf becomes the partial-output image
-  float *red = hbuf;       // [wave][n 64][RED_LDS]
+  float *red = hbuf;       // [wave][n o_pad][RED_LDS] (133 KB at four output tiles: runs over into the dead input image)
 #pragma unroll
-  for (int t2 = 0; t2 < 2; ++t2)
+  for (int t2 = 0; t2 < OT; ++t2)
 #pragma unroll
     for (int bt = 0; bt < 2; ++bt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int n = t2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        red[(wave * 64 + n) * RED_LDS + 32 * bt + r] = o[t2][bt][i];
+        red[(wave * o_pad + n) * RED_LDS + 32 * bt + r] = o[t2][bt][i];
       }
   __syncthreads();
   // ---- head: mean = sig * o + mu ; var = exp(2 log sig + o')   (models/pens/pe.py:815-835) -----------------------
   auto reduced = [&](int b, int n) -> float {
-    float v = red[(0 * 64 + n) * RED_LDS + b];
-    v += red[(1 * 64 + n) * RED_LDS + b];
-    v += red[(2 * 64 + n) * RED_LDS + b];
-    v += red[(3 * 64 + n) * RED_LDS + b];
+    float v = red[(0 * o_pad + n) * RED_LDS + b];
+    v += red[(1 * o_pad + n) * RED_LDS + b];
+    v += red[(2 * o_pad + n) * RED_LDS + b];
+    v += red[(3 * o_pad + n) * RED_LDS + b];
     return v + bias_l[2 * HIDS + n];
   };
+  // thread (row b = tid / 4, q = tid % 4) writes outputs n = q, q + 4, ...: the row index is read once and the
+  // iterations are independent, so their LDS reads are in flight together (one wave per SIMD: nobody else hides them)
   const int out = p.out_dim;
-  const float inv_out = 1.0f / (float)out;
-  for (int i = tid; i < ROWS * out; i += kThreadsS) {
-    const int b = (int)(((float)i + 0.5f) * inv_out);
-    const int n = i - b * out;
+  {
+    const int b = tid >> 2, q = tid & 3;
     const int rr = rows[b];
-    const float m = oconst[n] * reduced(b, n) + oconst[2 * out + n];
-    const float lv = oconst[out + n] + reduced(b, out + n);
-    if (rr >= 0) {
-      const size_t oo = ((size_t)e * p.ld_rows + rr) * out + n;
-      p.out0[oo] = m;
-      p.out1[oo] = __expf(lv);
+    const size_t obase = ((size_t)e * p.ld_rows + (rr >= 0 ? rr : 0)) * out;
+#pragma unroll
+    for (int u = 0; u < 4 * OT; ++u) {    // out <= 16 OT
+      const int n = q + 4 * u;
+      if (n < out) {
+        const float m = oconst[n] * reduced(b, n) + oconst[2 * out + n];
+        const float lv = oconst[out + n] + reduced(b, out + n);
+        if (rr >= 0) {
+          p.out0[obase + n] = m;
+          p.out1[obase + n] = __expf(lv);
+        }
+      }
     }
   }
   __syncthreads();         // the next item overwrites rows / bias / the images
@@ -407,13 +433,18 @@ int cmbpo_internal_launch_split(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
   const int tiles = cmbpo_ceil_div(a.n_rows, ROWS);
   k.m.tiles = tiles;
   k.m.n_items = tiles * m->ensemble;
-  const size_t lds = ((size_t)ROWS * HS + (size_t)ROWS * (k.slabs0 * 16 + 4) + 2 * HIDS + 64 + 3 * m->out_dim + ROWS) * sizeof(float);
+  const int OT = m->o_tiles;
+  CMBPO_REQUIRE(OT >= 1 && OT <= 4, "ens_split: %d output tiles", OT);
+  const size_t lds = ((size_t)ROWS * HS + (size_t)ROWS * (k.slabs0 * 16 + 4) + 2 * HIDS + OT * 32 + 3 * m->out_dim + ROWS) * sizeof(float);
   CMBPO_REQUIRE(lds <= 160 * 1024, "ens_split: LDS budget exceeded (%zu B)", lds);
-  static size_t attr_bytes = 0;
-  if (lds > attr_bytes) {
-    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ens_split_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_bytes = lds;
+  CMBPO_REQUIRE((size_t)4 * OT * 32 * RED_LDS <= (size_t)ROWS * HS + (size_t)ROWS * (k.slabs0 * 16 + 4),
+                "ens_split: partial-output image does not fit");
+  const void *kern = OT == 1 ? (const void *)ens_split_kernel<1> : OT == 2 ? (const void *)ens_split_kernel<2>
+                   : OT == 3 ? (const void *)ens_split_kernel<3> : (const void *)ens_split_kernel<4>;
+  static size_t attr_bytes[5] = {0, 0, 0, 0, 0};
+  if (lds > attr_bytes[OT]) {
+    CMBPO_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_bytes[OT] = lds;
   }
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -423,7 +454,10 @@ int cmbpo_internal_launch_split(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
     if (n_cu <= 0) n_cu = 256;
   }
   const int grid = k.m.n_items < n_cu ? k.m.n_items : n_cu;
-  hipLaunchKernelGGL(ens_split_kernel, dim3(grid), dim3(kThreadsS), lds, s, k);
+  if (OT == 1) hipLaunchKernelGGL(ens_split_kernel<1>, dim3(grid), dim3(kThreadsS), lds, s, k);
+  else if (OT == 2) hipLaunchKernelGGL(ens_split_kernel<2>, dim3(grid), dim3(kThreadsS), lds, s, k);
+  else if (OT == 3) hipLaunchKernelGGL(ens_split_kernel<3>, dim3(grid), dim3(kThreadsS), lds, s, k);
+  else hipLaunchKernelGGL(ens_split_kernel<4>, dim3(grid), dim3(kThreadsS), lds, s, k);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }

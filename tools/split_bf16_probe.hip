@@ -97,6 +97,69 @@ __global__ __launch_bounds__(256) void rate_kernel(float *out, int slabs) {
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// (3) what the slab loop of csrc/ens_split.hip pays next to its 48 MFMAs (4 n-tiles x 2 row halves x 6 terms), one wave
+// per SIMD: VAR 0 = the MFMAs alone; 1 = + the 12 weight-fragment loads of the next slab (L2-resident buffer, ping-pong
+// registers); 2 = + the split of 16 fresh float32 values into 3 x 2 bf16 fragments; 3 = both.
+template <int VAR>
+__global__ __launch_bounds__(256) void slab_kernel(const bf16x8 *w, float *out, int slabs) {
+  const int l = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x16 acc[4][2];
+  for (int t = 0; t < 4; ++t)
+    for (int b = 0; b < 2; ++b)
+      for (int i = 0; i < 16; ++i) acc[t][b][i] = 0.0f;
+  bf16x8 A[2][4][3], BX[2][3], BY[2][3];
+  float raw[16];
+  for (int j = 0; j < 16; ++j) raw[j] = 0.01f * (float)(l + j) - 0.3f;
+  const bf16x8 *wa = w + wave * 12 * 64 + l;
+  for (int t = 0; t < 4; ++t)
+    for (int i = 0; i < 3; ++i) { A[0][t][i] = wa[(t * 3 + i) * 64]; A[1][t][i] = A[0][t][i]; }
+  for (int i = 0; i < 3; ++i) { BX[0][i] = A[0][0][i]; BY[0][i] = A[0][1][i]; BX[1][i] = A[0][2][i]; BY[1][i] = A[0][3][i]; }
+  auto step = [&](int s, int cur) {
+    const int nxt = cur ^ 1;
+    if (VAR & 1) {
+      const bf16x8 *q = wa + (size_t)((s + 1) & 63) * 48 * 64;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) A[nxt][t][i] = q[(t * 3 + i) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (VAR & 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        __bf16 p1, p2, p3;
+        split3(raw[j], p1, p2, p3); BX[nxt][0][j] = p1; BX[nxt][1][j] = p2; BX[nxt][2][j] = p3;
+        split3(raw[8 + j], p1, p2, p3); BY[nxt][0][j] = p1; BY[nxt][1][j] = p2; BY[nxt][2][j] = p3;
+        raw[j] += 0.125f; raw[8 + j] -= 0.0625f;     // fresh values every slab
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bf16x8 *a = A[cur][t];
+      const bf16x8 *bx = (VAR & 2) ? BX[cur] : BX[0], *by = (VAR & 2) ? BY[cur] : BY[0];
+      acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bx[0], acc[t][0], 0, 0, 0);
+      acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bx[2], acc[t][0], 0, 0, 0);
+      acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bx[1], acc[t][0], 0, 0, 0);
+      acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bx[0], acc[t][0], 0, 0, 0);
+      acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bx[1], acc[t][0], 0, 0, 0);
+      acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bx[0], acc[t][0], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], by[0], acc[t][1], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], by[2], acc[t][1], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], by[1], acc[t][1], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], by[0], acc[t][1], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], by[1], acc[t][1], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], by[0], acc[t][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int s = 0; s < slabs; s += 2) { step(s, 0); step(s + 1, 1); }
+  float r = 0.0f;
+  for (int t = 0; t < 4; ++t)
+    for (int b = 0; b < 2; ++b)
+      for (int i = 0; i < 16; ++i) r += acc[t][b][i];
+  out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
 static double max_rel(const float *c, const double *ref, double scale) {
   double m = 0.0;
   for (int i = 0; i < 1024; ++i) m = fmax(m, fabs((double)c[i] - ref[i]) / scale);
@@ -169,5 +232,29 @@ int main() {
          "\"split_bf16_6_1acc\": %.1f, \"split_bf16_6_4acc\": %.1f}, \"speedup_4acc\": %.2f}\n",
          blocks, flop / ms[0][0] * 1e-9, flop / ms[0][1] * 1e-9, flop / ms[1][0] * 1e-9, flop / ms[1][1] * 1e-9,
          ms[0][1] / ms[1][1]);
+  // ---- slab loop variants ------------------------------------------------------------------------------------
+  {
+    bf16x8 *w; hipMalloc(&w, (size_t)64 * 48 * 64 * 16 + 4 * 12 * 64 * 16);
+    hipMemset(w, 0, (size_t)64 * 48 * 64 * 16 + 4 * 12 * 64 * 16);
+    const int sl = 4000;
+    float t[4];
+    for (int v = 0; v < 4; ++v) {
+      float best = 1e30f;
+      for (int rep = 0; rep < 3; ++rep) {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
+        if (v == 0) hipLaunchKernelGGL(slab_kernel<0>, dim3(blocks), dim3(256), 0, 0, w, out, sl);
+        if (v == 1) hipLaunchKernelGGL(slab_kernel<1>, dim3(blocks), dim3(256), 0, 0, w, out, sl);
+        if (v == 2) hipLaunchKernelGGL(slab_kernel<2>, dim3(blocks), dim3(256), 0, 0, w, out, sl);
+        if (v == 3) hipLaunchKernelGGL(slab_kernel<3>, dim3(blocks), dim3(256), 0, 0, w, out, sl);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float x; hipEventElapsedTime(&x, e0, e1);
+        if (x < best) best = x;
+      }
+      t[v] = best;
+    }
+    printf("{\"slab_loop_ns_per_slab\": {\"mfma_only\": %.1f, \"plus_12_loads\": %.1f, \"plus_split_16\": %.1f, \"plus_both\": %.1f}}\n",
+           t[0] * 1e6 / sl, t[1] * 1e6 / sl, t[2] * 1e6 / sl, t[3] * 1e6 / sl);
+  }
   return 0;
 }

@@ -736,6 +736,9 @@ int launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s, int head_override 
 
   if (head == CMBPO_HEAD_PROB && H == 512 && m->act == CMBPO_ACT_SWISH && m->o_tiles <= 4 && m->in_pad <= 64 && g_split_path)
     return cmbpo_internal_launch_split(m, a, s);
+  if (head == CMBPO_HEAD_DETMEAN && H == 128 && m->act == CMBPO_ACT_SWISH && m->o_width == 1 && m->in_pad <= 64 && E <= 8 &&
+      g_split_path)
+    return cmbpo_internal_launch_critic_split(m, a, s);
   const int BT = (H == 512 && g_block_rows == 64 && head != CMBPO_HEAD_TRAIN) ? 2 : 1;
   const int BB = 32 * BT;
   const int tiles = cmbpo_ceil_div(a.n_rows, BB);

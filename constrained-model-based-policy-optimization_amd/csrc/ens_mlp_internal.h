@@ -68,3 +68,5 @@ int cmbpo_internal_launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s, int
 // HEAD_PROB, 512-wide, swish: the same forward on the bf16 matrix cores (fp32 products as six bf16 MFMAs); `a` filled
 // as for cmbpo_internal_launch_mlp
 int cmbpo_internal_launch_split(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s);
+// HEAD_DETMEAN, 128-wide, swish, one output (the critics) on the same matrix path
+int cmbpo_internal_launch_critic_split(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s);

@@ -384,6 +384,168 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
   }  // persistent item loop
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The critics (HEAD_DETMEAN, 128 hidden units, one output; models/pens/pe.py:338-343,648-669) on the same matrix path.
+// At 128 hidden units a wave that owned one n-tile would split 8 values per 6 MFMAs -- VALU-bound -- so here waves own
+// ROWS: wave w of the 2-wave workgroup carries rows 32 w .. 32 w + 31 of the 64-row item through all 128 hidden units
+// (4 n-tiles: 24 MFMAs per 8 split values, the ratio of the 512-wide kernel).  A wave's rows are private to it from the
+// input image to the output, so the members' layers follow each other without a workgroup barrier; the single output
+// column is a VALU dot product on the h2 registers, the members' values are averaged in a register.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kThreadsC = 128;
+constexpr int HC = 128;
+constexpr int HSC = HC + 4;
+constexpr int kEMaxC = 8;
+
+// first weight fragments (slab 0) of a layer: the caller requests them ahead of the previous layer's epilogue, so the short
+// layers of a 128-wide member (2 and 8 slabs) do not start with an exposed L2 round trip each
+__device__ __forceinline__ void load_first_rows(Split3 (&a)[4], const bf16x8 *wp, int slabs, int lane) {
+  const size_t tstep = (size_t)slabs * 3 * 64;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const bf16x8 *q = wp + lane + t * tstep;
+    a[t].p1 = q[0]; a[t].p2 = q[64]; a[t].p3 = q[128];
+  }
+}
+
+// A0 holds the fragments of slab 0 on entry (load_first_rows) and is dead on return
+__device__ __forceinline__ void split_layer_rows(f32x16 (&acc)[4], Split3 (&A0)[4], const bf16x8 *wp, int slabs,
+                                                 const float *rows_img, int stride, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const bf16x8 *wa = wp + lane;
+  const size_t tstep = (size_t)slabs * 3 * 64;
+  const float *b0 = rows_img + (size_t)r * stride + 8 * h;
+  auto load_a = [&](Split3 (&a)[4], int s) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bf16x8 *q = wa + t * tstep + (size_t)s * 192;
+      a[t].p1 = q[0]; a[t].p2 = q[64]; a[t].p3 = q[128];
+    }
+  };
+  Split3 A1[4], B[2];
+  f32x4 R[2][2];
+  R[0][0] = *reinterpret_cast<const f32x4 *>(b0); R[0][1] = *reinterpret_cast<const f32x4 *>(b0 + 4);
+  B[0] = split8(R[0][0], R[0][1]);
+  const int sb1 = slabs > 1 ? 1 : 0;
+  R[1][0] = *reinterpret_cast<const f32x4 *>(b0 + 16 * sb1); R[1][1] = *reinterpret_cast<const f32x4 *>(b0 + 16 * sb1 + 4);
+  auto step = [&](int s, Split3 (&a_use)[4], Split3 (&a_ld)[4], const Split3 &b_use, Split3 &b_mk, const f32x4 (&raw_use)[2],
+                  f32x4 (&raw_ld)[2]) {
+    const int s1 = (s + 1 < slabs) ? s + 1 : s, s2 = (s + 2 < slabs) ? s + 2 : s1;
+    if (s + 1 < slabs) load_a(a_ld, s1);
+    const f32x4 n0 = *reinterpret_cast<const f32x4 *>(b0 + 16 * s2), n1 = *reinterpret_cast<const f32x4 *>(b0 + 16 * s2 + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    b_mk = split8(raw_use[0], raw_use[1]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) mfma6(acc[t], a_use[t], b_use);
+    __builtin_amdgcn_sched_barrier(0);
+    raw_ld[0] = n0; raw_ld[1] = n1;
+  };
+  int s = 0;
+  for (; s + 1 < slabs; s += 2) {
+    step(s, A0, A1, B[0], B[1], R[1], R[0]);
+    step(s + 1, A1, A0, B[1], B[0], R[0], R[1]);
+  }
+  if (s < slabs) step(s, A0, A1, B[0], B[1], R[1], R[0]);
+}
+
+__global__ __launch_bounds__(kThreadsC) void critic_split_kernel(const SplitArgs a) {
+  const MlpKernelArgs &p = a.m;
+  extern __shared__ f32x4 smem4[];
+  const int kpad0 = a.slabs0 * 16, XS = kpad0 + 4;
+  float *xs = reinterpret_cast<float *>(smem4);       // [64][XS] scaled input, zero padded
+  float *h1 = xs + 64 * XS;                           // [64][HSC]
+  float *cst = h1 + 64 * HSC;                         // per member: b0[128] | b1[128] | W2 column [128] | b2, pad
+  constexpr int CST = 3 * HC + 4;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int n_rows = p.n_rows_dev ? *p.n_rows_dev : p.n_rows;
+  const int row0 = blockIdx.x * 64;
+  if (row0 >= n_rows) return;
+  const int E = p.ensemble;
+  // ---- constants of all members (once per workgroup) ----------------------------------------------------------------
+  for (int i = tid; i < E * CST; i += kThreadsC) {
+    const int e = i / CST, k = i - e * CST;
+    float v = 0.0f;
+    if (k < HC) v = p.b0[(size_t)e * HC + k];
+    else if (k < 2 * HC) v = p.b1[(size_t)e * HC + (k - HC)];
+    else if (k < 3 * HC) {
+      const int kk = k - 2 * HC;      // column 0 of the packed W2: pack index of (k = kk, n = 0)
+      v = reinterpret_cast<const float *>(p.wp2 + (size_t)e * p.wp2_stride)[(((size_t)(kk >> 3)) * 64 + ((kk >> 2) & 1) * 32) * 4 + (kk & 3)];
+    } else if (k == 3 * HC) v = p.b2[(size_t)e * p.o_tiles * 32];
+    cst[i] = v;
+  }
+  // ---- this wave's 32 rows of the input image ------------------------------------------------------------------------
+  int my_row = -1;    // global row of batch row r of this wave (same in both lane halves)
+  {
+    const int rr0 = row0 + 32 * wave + r;
+    my_row = (rr0 < n_rows) ? (p.row_idx ? p.row_idx[rr0] : rr0) : -1;
+    const int c = lane & 7;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int b = 8 * pass + (lane >> 3);
+      const int rr = __shfl(my_row, b, 64);
+      for (int k = c; k < kpad0; k += 8) {
+        float x = 0.0f;
+        if (k < p.in_dim && rr >= 0) {
+          x = (k < p.obs_dim) ? p.obs[(size_t)rr * p.obs_dim + k] : p.act[(size_t)rr * p.act_dim + (k - p.obs_dim)];
+          if (p.in_mu) x = (x - p.in_mu[k]) / p.in_sig[k];   // TensorStandardScaler.transform, models/pens/utils.py:156
+        }
+        xs[(32 * wave + b) * XS + k] = x;
+      }
+    }
+  }
+  __syncthreads();   // the members' constants (shared); the input rows are this wave's own
+
+  const float *xrow = xs + (size_t)(32 * wave) * XS;
+  float *hrow = h1 + (size_t)(32 * wave) * HSC;
+  float member_sum = 0.0f;
+  const float o_sig = p.out_mu ? p.out_sig[0] : 1.0f, o_mu = p.out_mu ? p.out_mu[0] : 0.0f;
+  Split3 F[4];
+  load_first_rows(F, a.sp0, a.slabs0, lane);
+  for (int e = 0; e < E; ++e) {
+    const float *ce = cst + e * CST;
+    f32x16 acc[4];
+    auto init_bias = [&](const float *bias) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + t * 32 + 8 * q + 4 * h);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[t][4 * q + s] = bv[s];
+        }
+    };
+    init_bias(ce);
+    split_layer_rows(acc, F, a.sp0 + (size_t)e * a.sp0_stride, a.slabs0, xrow, XS, lane);
+    load_first_rows(F, a.sp1 + (size_t)e * a.sp1_stride, HC / 16, lane);      // in flight behind the swish / LDS image
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = swishf(acc[t][4 * q + s]);
+        *reinterpret_cast<f32x4 *>(hrow + (size_t)r * HSC + t * 32 + 8 * q + 4 * h) = v;   // read back by this wave only
+      }
+    init_bias(ce + HC);
+    split_layer_rows(acc, F, a.sp1 + (size_t)e * a.sp1_stride, HC / 16, hrow, HSC, lane);
+    if (e + 1 < E) load_first_rows(F, a.sp0 + (size_t)(e + 1) * a.sp0_stride, a.slabs0, lane);   // next member, behind the output dot
+    float partial = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 w = *reinterpret_cast<const f32x4 *>(ce + 2 * HC + t * 32 + 8 * q + 4 * h);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) partial = fmaf(swishf(acc[t][4 * q + s]), w[s], partial);
+      }
+    partial += __shfl_xor(partial, 32, 64);
+    member_sum += o_sig * (partial + ce[3 * HC]) + o_mu;
+  }
+  if (h == 0 && my_row >= 0) p.out0[my_row] = member_sum / (float)E;
+}
+
 }  // namespace
 
 // ---- host side -------------------------------------------------------------------------------------------------
@@ -458,6 +620,27 @@ int cmbpo_internal_launch_split(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
   else if (OT == 2) hipLaunchKernelGGL(ens_split_kernel<2>, dim3(grid), dim3(kThreadsS), lds, s, k);
   else if (OT == 3) hipLaunchKernelGGL(ens_split_kernel<3>, dim3(grid), dim3(kThreadsS), lds, s, k);
   else hipLaunchKernelGGL(ens_split_kernel<4>, dim3(grid), dim3(kThreadsS), lds, s, k);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+int cmbpo_internal_launch_critic_split(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
+  if (int rc = ensure_split(m, s)) return rc;
+  SplitArgs k{};
+  k.m = a;
+  const bf16x8 *base = reinterpret_cast<const bf16x8 *>(m->d_split);
+  k.sp0 = base + m->sp_off[0]; k.sp1 = base + m->sp_off[1]; k.sp2 = base + m->sp_off[2];
+  k.sp0_stride = m->sp_stride[0]; k.sp1_stride = m->sp_stride[1]; k.sp2_stride = m->sp_stride[2];
+  k.slabs0 = (m->in_pad + 15) / 16;
+  const int items = cmbpo_ceil_div(a.n_rows, 64);
+  const size_t lds = ((size_t)64 * (k.slabs0 * 16 + 4) + (size_t)64 * HSC + (size_t)m->ensemble * (3 * HC + 4)) * sizeof(float);
+  static size_t attr_bytes = 0;
+  if (lds > attr_bytes) {
+    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(critic_split_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_bytes = lds;
+  }
+  hipLaunchKernelGGL(critic_split_kernel, dim3(items), dim3(kThreadsC), lds, s, k);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }

@@ -68,7 +68,8 @@ int cmbpo_set_dispatch_mode(int mode);
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- every partial product exact, dropped terms <= 2^-24 |ab|,
  * measured error 6.2e-7 of sum|a_k b_k| at K = 512 against 7.6e-7 for the fp32 MFMA chain
  * (tools/split_bf16_probe.hip) -- at about twice the matrix rate.  Both pass the same parity tests.  The
- * environment variable CMBPO_ENS_SPLIT=0/1 sets the initial value.  Other shapes / heads always use fp32 MFMAs. */
+ * environment variable CMBPO_ENS_SPLIT=0/1 sets the initial value.  The switch also covers the critics
+ * (cmbpo_ens_predict_mean at 128 hidden units, one output); every other shape / head uses fp32 MFMAs. */
 #define CMBPO_ENS_FP32 0
 #define CMBPO_ENS_SPLIT_BF16 1
 int cmbpo_set_ens_matrix_path(int path);

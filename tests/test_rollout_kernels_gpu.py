@@ -89,13 +89,15 @@ def test_ens_forward_row_gather_and_split_inputs(hip_lib):
     assert np.isnan(got[:, untouched]).all()     # rows outside the list are never written
 
 
-@pytest.mark.parametrize("n", [1, 32, 100, 1000])
-def test_critic_predict_mean(hip_lib, n):
+@pytest.mark.parametrize("ens_path", [0, 1], indirect=True, ids=["fp32mfma", "splitbf16"])
+@pytest.mark.parametrize("obs_dim", [29, 45, 11])
+@pytest.mark.parametrize("n", [1, 32, 63, 65, 100, 1000])
+def test_critic_predict_mean(hip_lib, ens_path, n, obs_dim):
     _cuda()
     from cmbpo_amd import synthetic
     from cmbpo_amd.pens import PE
-    rng = np.random.default_rng(n)
-    E, obs_dim = 3, 29
+    rng = np.random.default_rng(n + obs_dim)
+    E = 3
     ws, bs = synthetic.ensemble_weights(rng, E, obs_dim, 128, 1, bias_scale=0.1)
     sc_in, sc_out = synthetic.scaler(rng, obs_dim), synthetic.scaler(rng, 1, hit_clamp=False)
     v = PE(obs_dim, 1, hidden_dims=(128, 128), num_networks=E, num_elites=2, loss="MSE",

@@ -78,12 +78,15 @@ __global__ __launch_bounds__(kThreads) void fakeenv_post_kernel(const PostArgs p
     for (int e = 0; e < kEMax; ++e) {
       if (e < E) {
         mu[e] = p.mean[e * mstride + base];
-        const float sd = sqrtf(p.var[e * mstride + base]);  // fake_env.py:104
-        // average_dkl: log, clip [-100, 1e8]; gaussian_kl_np: var = exp(2*log_std)
-        float l = logf(sd);
-        l = fminf(fmaxf(l, -100.0f), 1e8f);
+        // fake_env.py:104 std = sqrt(var); average_dkl: log_std = clip(log(std), -100, 1e8); gaussian_kl_np:
+        // var = exp(2 log_std).  Inside the clip range that is log_std = 0.5 log(var) and exp(2 log_std) = var up to
+        // rounding (the KL is compared at 1e-4, not bit for bit): one log instead of sqrt + log + exp per member.
+        const float v0 = p.var[e * mstride + base];
+        float l = __fmul_rn(0.5f, logf(v0));
+        const bool inside = l >= -100.0f && l <= 1e8f;       // false for NaN as well
+        if (!inside) l = fminf(fmaxf(logf(sqrtf(v0)), -100.0f), 1e8f);
         ls[e] = l;
-        vr[e] = expf(__fmul_rn(2.0f, l));
+        vr[e] = inside ? v0 : expf(__fmul_rn(2.0f, l));
       }
     }
     // ensemble epistemic variance over ALL members (np.var, axis 0), fake_env.py:112
@@ -113,10 +116,12 @@ __global__ __launch_bounds__(kThreads) void fakeenv_post_kernel(const PostArgs p
           const float dm = __fsub_rn(mu[c], mu[a]);
           dm2[a][c] = __fmul_rn(dm, dm);
         }
-    float den[kEMax];
+    // 1 / (var_c + 1e-10) once per member instead of a division per ordered pair (E - 1 times fewer divisions; the
+    // quotient differs from the reference's by an ulp at most)
+    float rden[kEMax];
 #pragma unroll
     for (int c = 0; c < kEMax; ++c)
-      if (c < E) den[c] = __fadd_rn(vr[c], 1e-10f);
+      if (c < E) rden[c] = __builtin_amdgcn_rcpf(__fadd_rn(vr[c], 1e-10f));   // v_rcp_f32: 1 ulp
     float acc = 0.0f;
 #pragma unroll
     for (int a = 0; a < kEMax; ++a) {
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(kThreads) void fakeenv_post_kernel(const PostArgs p
           if (c < E && c != a) {
             const float d2 = (a < c) ? dm2[a][c] : dm2[c][a];
             const float num = __fadd_rn(d2, vr[a]);
-            const float q = num / den[c];
+            const float q = __fmul_rn(num, rden[c]);
             float pre = __fmul_rn(0.5f, __fsub_rn(q, 1.0f));
             pre = __fsub_rn(__fadd_rn(pre, ls[c]), ls[a]);
             pre = fminf(fmaxf(pre, 0.0f), 1e10f);

@@ -736,8 +736,10 @@ int launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s, int head_override 
 
   if (head == CMBPO_HEAD_PROB && H == 512 && m->act == CMBPO_ACT_SWISH && m->o_tiles <= 4 && m->in_pad <= 64 && g_split_path)
     return cmbpo_internal_launch_split(m, a, s);
+  // (the critics' split kernel pays from ~30 k rows: below that a launch is one round of items and an item's latency
+  // counts -- 31 us for its three members in sequence on two waves against 19 us for the fp32 kernel's 32-row items)
   if (head == CMBPO_HEAD_DETMEAN && H == 128 && m->act == CMBPO_ACT_SWISH && m->o_width == 1 && m->in_pad <= 64 && E <= 8 &&
-      g_split_path)
+      g_split_path && a.n_rows >= 32768)
     return cmbpo_internal_launch_critic_split(m, a, s);
   const int BT = (H == 512 && g_block_rows == 64 && head != CMBPO_HEAD_TRAIN) ? 2 : 1;
   const int BB = 32 * BT;

@@ -27,9 +27,7 @@ namespace {
 
 constexpr int kThreadsS = 256;
 constexpr int HIDS = 512;
-constexpr int ROWS = 64;          // rows per item
 constexpr int HS = HIDS + 4;      // row stride of the activation image
-constexpr int RED_LDS = ROWS + 1;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -111,7 +109,8 @@ struct RawB {
 // Software pipeline, one slab deep, pinned with scheduling barriers (left alone the compiler sinks the weight loads
 // into the iteration that consumes them and every slab waits out an L2 round trip): while the 48 MFMAs of slab s issue,
 // the weight fragments of slab s + 1 are in flight, the B rows of slab s + 1 are split and those of s + 2 are read.
-__device__ __forceinline__ void split_layer(f32x16 (&acc)[NTS][2], const bf16x8 *wp, int slabs, const float *img, int stride,
+template <int BT>
+__device__ __forceinline__ void split_layer(f32x16 (&acc)[NTS][BT], const bf16x8 *wp, int slabs, const float *img, int stride,
                                             int wave, int lane) {
   const int r = lane & 31, h = lane >> 5;
   const bf16x8 *wa = wp + (size_t)(NTS * wave) * slabs * 3 * 64 + lane;
@@ -127,7 +126,11 @@ __device__ __forceinline__ void split_layer(f32x16 (&acc)[NTS][2], const bf16x8 
   auto read_b = [&](int s) {
     RawB v;
     v.x0 = *reinterpret_cast<const f32x4 *>(b0 + 16 * s); v.x1 = *reinterpret_cast<const f32x4 *>(b0 + 16 * s + 4);
-    v.y0 = *reinterpret_cast<const f32x4 *>(b1 + 16 * s); v.y1 = *reinterpret_cast<const f32x4 *>(b1 + 16 * s + 4);
+    if constexpr (BT == 2) {
+      v.y0 = *reinterpret_cast<const f32x4 *>(b1 + 16 * s); v.y1 = *reinterpret_cast<const f32x4 *>(b1 + 16 * s + 4);
+    } else {
+      v.y0 = v.x0; v.y1 = v.x1;
+    }
     return v;
   };
   // two register sets in ping-pong (a copy "current = next" per slab is 32 moves in front of the MFMAs)
@@ -135,7 +138,8 @@ __device__ __forceinline__ void split_layer(f32x16 (&acc)[NTS][2], const bf16x8 
   RawB R[2];
   load_a(A[0], 0);
   R[0] = read_b(0);
-  BX[0] = split8(R[0].x0, R[0].x1); BY[0] = split8(R[0].y0, R[0].y1);
+  BX[0] = split8(R[0].x0, R[0].x1);
+  if constexpr (BT == 2) BY[0] = split8(R[0].y0, R[0].y1);
   R[1] = read_b(slabs > 1 ? 1 : 0);
   auto step = [&](int s, Split3 (&a_use)[NTS], Split3 (&a_ld)[NTS], const Split3 &bx_use, const Split3 &by_use, Split3 &bx_mk,
                   Split3 &by_mk, const RawB &raw_use, RawB &raw_ld) {
@@ -143,11 +147,12 @@ __device__ __forceinline__ void split_layer(f32x16 (&acc)[NTS][2], const bf16x8 
     __builtin_amdgcn_sched_barrier(0);
     load_a(a_ld, s1);
     const RawB nn = read_b(s2);
-    bx_mk = split8(raw_use.x0, raw_use.x1); by_mk = split8(raw_use.y0, raw_use.y1);
+    bx_mk = split8(raw_use.x0, raw_use.x1);
+    if constexpr (BT == 2) by_mk = split8(raw_use.y0, raw_use.y1);
 #pragma unroll
     for (int t = 0; t < NTS; ++t) {
       mfma6(acc[t][0], a_use[t], bx_use);
-      mfma6(acc[t][1], a_use[t], by_use);
+      if constexpr (BT == 2) mfma6(acc[t][1], a_use[t], by_use);
     }
     // A wave issues in order: whatever stands between two MFMAs in the instruction stream runs in the shadow of the
     // first (its 32 cycles in the pipe, 8 of them holding the issue port), whatever stands in front of a run of MFMAs
@@ -155,7 +160,7 @@ __device__ __forceinline__ void split_layer(f32x16 (&acc)[NTS][2], const bf16x8 
     // of issue) every fourth gap, the four LDS reads in the first gaps, three of the split's VALU instructions in
     // every other gap.
 #pragma unroll
-    for (int i = 0; i < 12 * NTS; ++i) {
+    for (int i = 0; i < 6 * BT * NTS; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
       if ((i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // 1 VMEM read
       else __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                  // 3 VALU
@@ -172,8 +177,10 @@ __device__ __forceinline__ void split_layer(f32x16 (&acc)[NTS][2], const bf16x8 
   if (s < slabs) step(s, A[0], A[1], BX[0], BY[0], BX[1], BY[1], R[1], R[0]);
 }
 
-template <int OT>   // output n-tiles: 2 out_dim <= 32 OT
-__global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a) {
+template <int OT, int BT>   // output n-tiles (2 out_dim <= 32 OT); 32-row halves per item: 2 (64 rows), or 1 when 64-row items
+                            // would leave CUs idle (small rollout batches: an item's latency is the step's)
+__global__ __launch_bounds__(kThreadsS, (BT == 1 ? 2 : 1)) void ens_split_kernel(const SplitArgs a) {
+  constexpr int ROWS = 32 * BT, RED_LDS = ROWS + 1, TPR = kThreadsS / ROWS;   // TPR threads stage one row
   const MlpKernelArgs &p = a.m;
   extern __shared__ f32x4 smem4[];
   float *hbuf = reinterpret_cast<float *>(smem4);          // [ROWS][HS]; later the partial outputs [4][64][RED_LDS]
@@ -195,8 +202,8 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
   // Persistent workgroups (one per CU: 150 KB of LDS): with a single workgroup per CU nothing else covers an item's
   // prologue, so the NEXT item's input rows are gathered into registers behind the 512 x 512 layer of the current one
   // (row index first, then the dependent row gather), and the dispatcher's turnaround between items disappears.
-  constexpr int XPRE = 16;            // >= kpad0 / 4 (in_pad <= 64)
-  const int xc = tid & 3, xb = tid >> 2;
+  constexpr int XPRE = 64 / TPR;      // >= kpad0 / TPR (in_pad <= 64)
+  const int xc = tid % TPR, xb = tid / TPR;
   float xpre[XPRE];
   int rr_pre = -1;
   auto item_rows = [&](int it, int &e_out, int &row0_out) {
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
   auto fetch_x = [&]() {
 #pragma unroll
     for (int u = 0; u < XPRE; ++u) {
-      const int k = xc + 4 * u;
+      const int k = xc + TPR * u;
       float x = 0.0f;
       if (k < p.in_dim && rr_pre >= 0) {
         x = (k < p.obs_dim) ? p.obs[(size_t)rr_pre * p.obs_dim + k] : p.act[(size_t)rr_pre * p.act_dim + (k - p.obs_dim)];
@@ -257,13 +264,13 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
   if (xc == 0) rows[xb] = rr_pre;
 #pragma unroll
   for (int u = 0; u < XPRE; ++u) {
-    const int k = xc + 4 * u;
+    const int k = xc + TPR * u;
     if (k < kpad0) xs[xb * XS + k] = xpre[u];
   }
   fetch_row(item + gridDim.x);     // the next item's row index: lands during layer 0
   __syncthreads();
 
-  f32x16 acc[NTS][2];
+  f32x16 acc[NTS][BT];
   auto init_bias = [&](const float *bias) {
 #pragma unroll
     for (int t = 0; t < NTS; ++t)
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
       for (int q = 0; q < 4; ++q) {
         const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + (NTS * wave + t) * 32 + 8 * q + 4 * h);
 #pragma unroll
-        for (int bt = 0; bt < 2; ++bt)
+        for (int bt = 0; bt < BT; ++bt)
 #pragma unroll
           for (int s = 0; s < 4; ++s) acc[t][bt][4 * q + s] = bv[s];
       }
@@ -280,21 +287,21 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
 #pragma unroll
     for (int t = 0; t < NTS; ++t)
 #pragma unroll
-      for (int bt = 0; bt < 2; ++bt)
+      for (int bt = 0; bt < BT; ++bt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][bt][i] = swishf(acc[t][bt][i]);
   };
 
   // ---- layer 0: in -> 512 -----------------------------------------------------------------------------------
   init_bias(bias_l);
-  split_layer(acc, a.sp0 + (size_t)e * a.sp0_stride, a.slabs0, xs, XS, wave, lane);
+  split_layer<BT>(acc, a.sp0 + (size_t)e * a.sp0_stride, a.slabs0, xs, XS, wave, lane);
   swish_acc();
 #pragma unroll
   for (int t = 0; t < NTS; ++t)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int bt = 0; bt < 2; ++bt) {
+      for (int bt = 0; bt < BT; ++bt) {
         f32x4 v;
 #pragma unroll
         for (int s = 0; s < 4; ++s) v[s] = acc[t][bt][4 * q + s];
@@ -305,14 +312,14 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
   fetch_bias(item + gridDim.x);
   // ---- layer 1: 512 -> 512 ----------------------------------------------------------------------------------
   init_bias(bias_l + HIDS);
-  split_layer(acc, a.sp1 + (size_t)e * a.sp1_stride, HIDS / 16, hbuf, HS, wave, lane);
+  split_layer<BT>(acc, a.sp1 + (size_t)e * a.sp1_stride, HIDS / 16, hbuf, HS, wave, lane);
   swish_acc();
   // ---- layer 2: 512 -> 2 out (64 padded), K split over the waves, B operand = this wave's h2 registers ----------
-  f32x16 o[OT][2];
+  f32x16 o[OT][BT];
 #pragma unroll
   for (int t2 = 0; t2 < OT; ++t2)
 #pragma unroll
-    for (int bt = 0; bt < 2; ++bt)
+    for (int bt = 0; bt < BT; ++bt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[t2][bt][i] = 0.0f;
   {
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
           wa[t2].p1 = q[0]; wa[t2].p2 = q[64]; wa[t2].p3 = q[128];
         }
 #pragma unroll
-        for (int bt = 0; bt < 2; ++bt) {
+        for (int bt = 0; bt < BT; ++bt) {
           f32x4 lo, hi;
 #pragma unroll
           for (int j = 0; j < 4; ++j) { lo[j] = acc[t][bt][8 * half + j]; hi[j] = acc[t][bt][8 * half + 4 + j]; }
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
 #pragma unroll
   for (int t2 = 0; t2 < OT; ++t2)
 #pragma unroll
-    for (int bt = 0; bt < 2; ++bt)
+    for (int bt = 0; bt < BT; ++bt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int n = t2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -360,16 +367,16 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
     v += red[(3 * o_pad + n) * RED_LDS + b];
     return v + bias_l[2 * HIDS + n];
   };
-  // thread (row b = tid / 4, q = tid % 4) writes outputs n = q, q + 4, ...: the row index is read once and the
+  // thread (row b = tid / TPR, q = tid % TPR) writes outputs n = q, q + TPR, ...: the row index is read once and the
   // iterations are independent, so their LDS reads are in flight together (one wave per SIMD: nobody else hides them)
   const int out = p.out_dim;
   {
-    const int b = tid >> 2, q = tid & 3;
+    const int b = tid / TPR, q = tid % TPR;
     const int rr = rows[b];
     const size_t obase = ((size_t)e * p.ld_rows + (rr >= 0 ? rr : 0)) * out;
 #pragma unroll
-    for (int u = 0; u < 4 * OT; ++u) {    // out <= 16 OT
-      const int n = q + 4 * u;
+    for (int u = 0; u < 16 * OT / TPR; ++u) {    // out <= 16 OT
+      const int n = q + TPR * u;
       if (n < out) {
         const float m = oconst[n] * reduced(b, n) + oconst[2 * out + n];
         const float lv = oconst[out + n] + reduced(b, out + n);
@@ -395,7 +402,6 @@ __global__ __launch_bounds__(kThreadsS) void ens_split_kernel(const SplitArgs a)
 constexpr int kThreadsC = 128;
 constexpr int HC = 128;
 constexpr int HSC = HC + 4;
-constexpr int kEMaxC = 8;
 
 // first weight fragments (slab 0) of a layer: the caller requests them ahead of the previous layer's epilogue, so the short
 // layers of a 128-wide member (2 and 8 slabs) do not start with an exposed L2 round trip each
@@ -592,22 +598,8 @@ int cmbpo_internal_launch_split(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
   k.sp0 = base + m->sp_off[0]; k.sp1 = base + m->sp_off[1]; k.sp2 = base + m->sp_off[2];
   k.sp0_stride = m->sp_stride[0]; k.sp1_stride = m->sp_stride[1]; k.sp2_stride = m->sp_stride[2];
   k.slabs0 = (m->in_pad + 15) / 16;
-  const int tiles = cmbpo_ceil_div(a.n_rows, ROWS);
-  k.m.tiles = tiles;
-  k.m.n_items = tiles * m->ensemble;
   const int OT = m->o_tiles;
   CMBPO_REQUIRE(OT >= 1 && OT <= 4, "ens_split: %d output tiles", OT);
-  const size_t lds = ((size_t)ROWS * HS + (size_t)ROWS * (k.slabs0 * 16 + 4) + 2 * HIDS + OT * 32 + 3 * m->out_dim + ROWS) * sizeof(float);
-  CMBPO_REQUIRE(lds <= 160 * 1024, "ens_split: LDS budget exceeded (%zu B)", lds);
-  CMBPO_REQUIRE((size_t)4 * OT * 32 * RED_LDS <= (size_t)ROWS * HS + (size_t)ROWS * (k.slabs0 * 16 + 4),
-                "ens_split: partial-output image does not fit");
-  const void *kern = OT == 1 ? (const void *)ens_split_kernel<1> : OT == 2 ? (const void *)ens_split_kernel<2>
-                   : OT == 3 ? (const void *)ens_split_kernel<3> : (const void *)ens_split_kernel<4>;
-  static size_t attr_bytes[5] = {0, 0, 0, 0, 0};
-  if (lds > attr_bytes[OT]) {
-    CMBPO_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_bytes[OT] = lds;
-  }
   static int n_cu = 0;
   if (n_cu == 0) {
     hipDeviceProp_t prop;
@@ -615,11 +607,33 @@ int cmbpo_internal_launch_split(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
   }
-  const int grid = k.m.n_items < n_cu ? k.m.n_items : n_cu;
-  if (OT == 1) hipLaunchKernelGGL(ens_split_kernel<1>, dim3(grid), dim3(kThreadsS), lds, s, k);
-  else if (OT == 2) hipLaunchKernelGGL(ens_split_kernel<2>, dim3(grid), dim3(kThreadsS), lds, s, k);
-  else if (OT == 3) hipLaunchKernelGGL(ens_split_kernel<3>, dim3(grid), dim3(kThreadsS), lds, s, k);
-  else hipLaunchKernelGGL(ens_split_kernel<4>, dim3(grid), dim3(kThreadsS), lds, s, k);
+  // 64-row items halve the weight stream per row; while 32-row items still find a CU each (small rollout batches, where
+  // an item's latency is the step's) they take 0.8 of a 64-row item's time.  Measured, AntSafe shapes: 42 / 42 / 45 us
+  // at 256 / 512 / 1000 rows against 51 / 52 / 54 us; at 2000 rows 32-row items would share CUs: 74 us against 62.
+  const int BT = (cmbpo_ceil_div(a.n_rows, 32) * m->ensemble <= n_cu) ? 1 : 2;
+  const int rows = 32 * BT;
+  const int tiles = cmbpo_ceil_div(a.n_rows, rows);
+  k.m.tiles = tiles;
+  k.m.n_items = tiles * m->ensemble;
+  const size_t img = (size_t)rows * HS + (size_t)rows * (k.slabs0 * 16 + 4);
+  const size_t lds = (img + 2 * HIDS + OT * 32 + 3 * m->out_dim + rows) * sizeof(float);
+  CMBPO_REQUIRE(lds <= 160 * 1024, "ens_split: LDS budget exceeded (%zu B)", lds);
+  CMBPO_REQUIRE((size_t)4 * OT * 32 * (rows + 1) <= img, "ens_split: partial-output image does not fit");
+  const int resident = (BT == 1 ? 2 : 1) * n_cu;
+  const int grid = k.m.n_items < resident ? k.m.n_items : resident;
+  static size_t attr_bytes[5][3] = {};
+#define CMBPO_SPLIT_CASE(OT_, BT_)                                                                                   \
+  if (OT == OT_ && BT == BT_) {                                                                                      \
+    if (lds > attr_bytes[OT_][BT_]) {                                                                                \
+      CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ens_split_kernel<OT_, BT_>),                \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
+      attr_bytes[OT_][BT_] = lds;                                                                                    \
+    }                                                                                                                \
+    hipLaunchKernelGGL((ens_split_kernel<OT_, BT_>), dim3(grid), dim3(kThreadsS), lds, s, k);                       \
+  }
+  CMBPO_SPLIT_CASE(1, 1) CMBPO_SPLIT_CASE(2, 1) CMBPO_SPLIT_CASE(3, 1) CMBPO_SPLIT_CASE(4, 1)
+  CMBPO_SPLIT_CASE(1, 2) CMBPO_SPLIT_CASE(2, 2) CMBPO_SPLIT_CASE(3, 2) CMBPO_SPLIT_CASE(4, 2)
+#undef CMBPO_SPLIT_CASE
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }

@@ -40,7 +40,7 @@ def _dyn_model(rng, task, hidden=512, E=7):
 
 @pytest.mark.parametrize("ens_path", [0, 1], indirect=True, ids=["fp32mfma", "splitbf16"])
 @pytest.mark.parametrize("task", ["AntSafe-v2", "HalfCheetahSafe-v2", "HopperSafe-v2", "HumanoidSafe-v2"])
-@pytest.mark.parametrize("n", [1, 31, 32, 33, 63, 64, 65, 257])
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 63, 64, 65, 257, 1200, 2431])   # more than 36 tiles of 32 rows x 7 members: 64-row items
 def test_ens_forward_matches_oracle(hip_lib, ens_path, task, n):
     _cuda()
     rng = np.random.default_rng(zlib.crc32(f"{task}/{n}".encode()))     # stable across processes (str hash is salted)
@@ -91,7 +91,7 @@ def test_ens_forward_row_gather_and_split_inputs(hip_lib):
 
 @pytest.mark.parametrize("ens_path", [0, 1], indirect=True, ids=["fp32mfma", "splitbf16"])
 @pytest.mark.parametrize("obs_dim", [29, 45, 11])
-@pytest.mark.parametrize("n", [1, 32, 63, 65, 100, 1000])
+@pytest.mark.parametrize("n", [1, 32, 63, 65, 100, 1000, 32768 + 37])    # from 32768 rows: the split path's own kernel
 def test_critic_predict_mean(hip_lib, ens_path, n, obs_dim):
     _cuda()
     from cmbpo_amd import synthetic

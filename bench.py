@@ -1,6 +1,7 @@
 """bench.py -- imagined env-steps/s of the MI355X-native CMBPO rollout (+ CPO update ms).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--branches B] [--task AntSafe-v2]
+                    [--scaling weak|strong] [--maxroll T]
 
 One "step" = one full imagined-rollout phase of the reference trainer on one batch of start states:
 ``ModelSampler.reset -> sample() x (maxroll-1) -> finish_all_paths -> ModelBuffer.get()``
@@ -11,17 +12,94 @@ with the inputs (start states, weights) already resident in HBM.  metric value =
 Workload at N = 1: AntSafe-v2 shapes (obs 29, act 8), 7-member 512x512 swish ensemble, 5 elites, 3+3
 critic members, 128x128 tanh policy, B = 100 000 branches per GPU, maxroll 35 (34 stored steps),
 fixed-horizon mode -- the north-star configuration ("AntSafe 7-ensemble 100k-branch rollouts at
-1 MI355X").  N > 1: every rank rolls out its own B branches (weak scaling, no data-path collective;
-the only collectives are the advantage statistics of get()).  Synthetic seeded weights / states.
+1 MI355X").  N > 1, one process per GPU: ``--scaling weak`` (default) rolls out B branches on every rank,
+``--scaling strong`` shards B branches over the ranks as contiguous blocks of global branch ids (BASELINE
+config 4: ``--gpus 4 --scaling strong``; config 5: ``--gpus 8 --scaling strong --branches 1000000 --maxroll 26``).
+The data path has no collective; per step the ranks exchange three host scalars (global alive ratio, the
+reference's `alive_ratio`), per get() the advantage statistics.  Synthetic seeded weights / states.
+
+Launch: under ``torch.distributed.run`` (RANK / WORLD_SIZE set) every process is one rank.  Started plainly as
+``python bench.py --gpus N`` with N > 1, this process becomes a launcher (the reference's analogue is
+``mpi_fork``, utilities/mpi_tools.py:7-37): it starts N rank processes with RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_ADDR / MASTER_PORT set, relays rank 0's JSON line and exits with the first non-zero exit code.  The
+launcher never imports torch or touches the GPU, and nothing is exec'ed from a process that has.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--branches", type=int, default=100000,
+                    help="rollout branches per GPU (--scaling weak) or in total (--scaling strong)")
+    ap.add_argument("--task", default="AntSafe-v2")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--maxroll", type=int, default=35, help="max_path_length of the rollout (stored steps = maxroll - 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline rollout only (no update / training / sub-configs)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous, one all-reduce and the JSON line only (launcher test on machines without a GPU)")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args, argv):
+    """Launcher half of ``python bench.py --gpus N``: N rank processes of this same script, one per GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr, text=(rank == 0)))
+    line = None
+    for out in procs[0].stdout:          # rank 0 prints the one JSON line; anything else it prints is passed on
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        else:
+            print(out, file=sys.stderr, flush=True)
+    rc = 0
+    deadline = time.time() + 600
+    for p in procs:
+        try:
+            code = p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()                     # the exact process we started
+            code = p.wait()
+        rc = rc or code
+    if rc == 0 and line is None:
+        print("bench.py launcher: rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    if rc == 0:
+        n = json.loads(line).get("n_gpus")
+        if n != args.gpus:
+            print(f"bench.py launcher: result line says n_gpus = {n}, expected {args.gpus}", file=sys.stderr)
+            rc = 1
+    if rc == 0:
+        print(line, flush=True)
+    return rc
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _args = parse_args()
+    if _args.gpus > 1:                   # before torch is imported: the launcher never initialises a GPU
+        sys.exit(spawn_ranks(_args, sys.argv[1:]))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -29,7 +107,7 @@ import torch  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense
 SPLIT_TERMS = 6                 # bf16 MFMAs per float32 product on the split path (csrc/ens_split.hip)
-MAXROLL = 35
+MAXROLL = 35                    # default max_path_length (--maxroll)
 
 
 class _Space:
@@ -55,7 +133,7 @@ def build_world(seed, task, hidden=512, E=7):
                 elites=[0, 2, 3, 5, 6])
 
 
-def build_hip(w, task, B, device, comm=None):
+def build_hip(w, task, B, device, comm=None, maxroll=MAXROLL, mode="schedule"):
     from cmbpo_amd.cpo_policy import CPOPolicy
     from cmbpo_amd.fake_env import FakeEnv
     from cmbpo_amd.model_sampler import ModelSampler
@@ -78,9 +156,9 @@ def build_hip(w, task, B, device, comm=None):
         observation_space, action_space = _Space(D), _Space(A)
 
     env = FakeEnv(_Env(), task, model, True, True, False)
-    pool = ModelBuffer(B, D, A, MAXROLL, device=device, comm=comm)
+    pool = ModelBuffer(B, D, A, maxroll, device=device, comm=comm)
     pool.initialize(policy.pi_info_shapes, gamma=0.99, lam=0.95, cost_gamma=0.97, cost_lam=0.5)
-    sampler = ModelSampler(max_path_length=MAXROLL, batch_size=B, rollout_mode="schedule", comm=comm)
+    sampler = ModelSampler(max_path_length=maxroll, batch_size=B, rollout_mode=mode, comm=comm)
     sampler.initialize(env, policy, pool)
     return sampler, pool, env, policy
 
@@ -210,16 +288,35 @@ def cpu_baseline(w, task, seconds=20.0):
                        f"{steps} steps of the same workload + finish/get, {dt:.1f} s")
 
 
+def dry_run(args):
+    """Launcher / rendezvous check without a GPU: every rank joins, one all-reduce, rank 0 prints the line."""
+    import cmbpo_amd  # noqa: F401
+    from cmbpo_amd.dist import Comm
+    comm = Comm.init_from_env(None if torch.cuda.is_available() else "gloo")
+    seen = torch.zeros(max(comm.world, 1), dtype=torch.float64)
+    seen[comm.rank] = 1.0
+    comm.all_reduce_sum(seen)
+    comm.barrier()
+    if comm.world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the job has {comm.world} ranks", file=sys.stderr)
+        sys.exit(2)
+    if comm.rank == 0:
+        print(json.dumps({"metric": "imagined env-steps/sec (ensemble rollout) + CPO update ms", "value": None,
+                          "unit": "imagined env-steps/s", "n_gpus": comm.world, "steps": args.steps,
+                          "warmup": args.warmup, "scaling": args.scaling, "dry_run": True,
+                          "ranks_seen": int(seen.sum().item())}), flush=True)
+    comm.barrier()
+
+
+def shard_of(total, rank, world):
+    """Contiguous block of global branch ids of one rank: [lo, hi)."""
+    return (total * rank) // world, (total * (rank + 1)) // world
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--branches", type=int, default=100000, help="rollout branches per GPU")
-    ap.add_argument("--task", default="AntSafe-v2")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    args = ap.parse_args()
+    args = parse_args()
+    if args.dry_run:
+        return dry_run(args)
 
     import cmbpo_amd  # noqa: F401
     from cmbpo_amd import _lib, synthetic
@@ -232,13 +329,21 @@ def main():
     comm = Comm.init_from_env("nccl")
     comm.device = device
     rank, world = comm.rank, comm.world
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:      # never fall back to fewer ranks than asked for
+        print(f"bench.py: --gpus {args.gpus} but the job has {world} rank(s)", file=sys.stderr)
+        sys.exit(2)
 
-    task, B = args.task, args.branches
+    task, maxroll = args.task, args.maxroll
+    if args.scaling == "strong":   # the job's B branches as contiguous shards of global branch ids
+        lo, hi = shard_of(args.branches, rank, world)
+        B = hi - lo
+        all_states = synthetic.start_states(np.random.default_rng(100), args.branches, task)
+        start = torch.from_numpy(all_states[lo:hi]).to(device)
+    else:
+        B = args.branches
+        start = torch.from_numpy(synthetic.start_states(np.random.default_rng(100 + rank), B, task)).to(device)
     w = build_world(0, task)
-    sampler, pool, env, policy = build_hip(w, task, B, device, comm if world > 1 else None)
-    rng = np.random.default_rng(100 + rank)
-    start = torch.from_numpy(synthetic.start_states(rng, B, task)).to(device)
+    sampler, pool, env, policy = build_hip(w, task, B, device, comm if world > 1 else None, maxroll)
 
     for _ in range(args.warmup):
         rollout_phase(sampler, pool, start)
@@ -255,6 +360,7 @@ def main():
     dt = time.perf_counter() - t0
     events, env.kernel_events = env.kernel_events, None
 
+    extras = not args.no_extras
     # Metric B: CPO trust-region update (update_policy, algorithms/cmbpo.py:357) on the rollout's samples
     _, res = rollout_phase(sampler, pool, start)
     n_full = int(res[0].shape[0])
@@ -313,14 +419,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{task} imagined rollout: E={E} x ({D + A}->{H}->{H}->{2 * (D + 1)}) swish ensemble, 5 elites, "
-                                   f"3+3 critics 128x128, tanh policy 128x128, B={B} branches/GPU, maxroll 35 "
-                                   f"(34 steps), reset->sample*->finish_all_paths->get()",
-                       "branches_per_gpu": B, "horizon": MAXROLL - 1, "task": task,
+                                   f"3+3 critics 128x128, tanh policy 128x128, "
+                                   + (f"B={args.branches} branches sharded over {world} GPU(s)" if args.scaling == "strong"
+                                      else f"B={B} branches/GPU")
+                                   + f", maxroll {maxroll} ({maxroll - 1} steps), reset->sample*->finish_all_paths->get()",
+                       "branches_per_gpu": B, "branches_total": args.branches if args.scaling == "strong" else B * world,
+                       "horizon": maxroll - 1, "task": task,
                        "samples_per_step": tot / args.steps,
                        "arithmetic": ("float32 inputs, outputs and accumulation; the ensemble forward's float32 products run as six "
                                       "exact bf16 partial products each (operands split exactly into 3 bf16 pieces; measured error "

@@ -1,0 +1,44 @@
+"""`python bench.py --gpus N` must start N ranks itself (the reference's analogue is
+``mpi_fork``, utilities/mpi_tools.py:7-37).  CPU, gloo, world 2: the launcher half and the rendezvous of the rank half
+run end to end (`--dry-run`: no kernels -- those need a GPU; the N-rank rollout itself is covered on the GPU box by
+tests/test_world2_gpu.py and `bench.py --gpus 2` under CMBPO_DIST_BACKEND=gloo)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(argv, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True,
+                          text=True, timeout=240)
+
+
+def test_gpus2_spawns_two_ranks_and_reports_them():
+    r = _run(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"], {"CMBPO_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # exactly one JSON line, relayed from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+
+
+def test_world_mismatch_is_an_error_not_a_silent_one_rank_run():
+    # a torchrun-style environment with fewer ranks than --gpus asks for must not fall back to that many ranks
+    r = _run(["--gpus", "4", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, drop=())
+    assert r.returncode != 0
+    assert "--gpus 4" in r.stderr
+
+
+def test_strong_scaling_shards_are_a_partition():
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    for total, world in ((100000, 4), (1000000, 8), (1001, 3), (7, 8)):
+        blocks = [bench.shard_of(total, r, world) for r in range(world)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+        assert max(h - l for l, h in blocks) - min(h - l for l, h in blocks) <= 1

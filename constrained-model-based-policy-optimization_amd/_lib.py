@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libcmbpo_hip.so")
 ACT_SWISH, ACT_TANH = 0, 1
 HEAD_PROB, HEAD_DETMEAN, HEAD_GAUSS_PI = 0, 1, 2
 LOSS_DEFAULT, LOSS_NLL = 0, 1      # cmbpo_trainer_set_loss
-ENS_FP32, ENS_SPLIT_BF16 = 0, 1    # cmbpo_set_ens_matrix_path
+ENS_FP32, ENS_SPLIT_BF16, ENS_SPLIT_F16 = 0, 1, 2    # cmbpo_set_ens_matrix_path
 TASK_DEFAULT, TASK_HCS, TASK_ANTSAFE = 0, 1, 2
 
 # models/statics.py:56-69 -- task name -> rule id
@@ -38,6 +38,7 @@ SIGNATURES = {
     "cmbpo_set_dispatch_mode": (_i, [_i]),
     "cmbpo_set_ens_matrix_path": (_i, [_i]),
     "cmbpo_get_ens_matrix_path": (_i, []),
+    "cmbpo_set_ens_f16_min_rows": (_i, [_i]),
     "cmbpo_mlp_create": (_i, [C.POINTER(_p), _i, _i, _i, _i, _i, _i]),
     "cmbpo_mlp_destroy": (None, [_p]),
     "cmbpo_mlp_load": (_i, [_p] * 13),

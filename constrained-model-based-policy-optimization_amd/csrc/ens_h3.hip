@@ -1,0 +1,656 @@
+// Ensemble forward (HEAD_PROB, 512-wide, swish) with every float32 product carried by THREE f16 MFMAs.
+//
+// Same function as ens_mlp_kernel<512, *, swish, prob> / ens_split_kernel (models/pens/pe.py:688-697,789-838,
+// fc.py:74-95, models/pens/utils.py:156-187): one item = 128 rows of one member through
+//     x -> swish(x W0 + b0) -> swish(. W1 + b1) -> . W2 + b2 -> (mean, var).
+//
+// Arithmetic.  A float32 number a, lifted by a power of two s into the top of the f16 range, splits into two f16
+// pieces a1 = f16(a s), a2 = f16(a s - a1) (the difference is exact in float32): 11 + 1 + 11 significant bits, i.e.
+// a s = (a1 + a2)(1 + d), |d| <= 2^-24 -- a float32 rounding.  Then
+//     a . b  =  [a2 b1 + a1 b2 + a1 b1] / (s t)  +  O(2^-23 |ab|)
+// as three v_mfma_f32_32x32x16_f16 with fp32 accumulation (every partial product exact, smallest first; the dropped
+// a2 b2 <= 2^-24 |ab|).  Measured (tools/split_f16_probe.hip): error 3.2e-7 of sum|a_k b_k| at K = 512 -- the fp32 MFMA
+// chain 7.6e-7, the six-term bf16 split 6.2e-7 -- at half the matrix instructions of the latter.
+// Scales (all powers of two, so scaling and unscaling are exact):
+//   * weights: one per (member, layer), max |W| s in [2^13, 2^14)  (h3_stats_kernel, whenever the packs change);
+//   * activations: one per (row, layer), from a BOUND known before the layer runs: the row's max |x| is taken when the
+//     input is staged, and |h1| <= |z1| <= L1 m0 + B, |h2| <= L2 bound1 + B' with L = the member's largest column 1-norm
+//     of W and B = max |b| (swish(z) <= |z|).  bound t in [2^13, 2^14): no piece can overflow for any finite input, no
+//     cross-wave reduction is needed, and a loose bound only moves the SMALLEST elements of a row towards the f16
+//     subnormals: an element keeps full relative precision down to 2^-17 of the bound, below that its absolute error is
+//     <= 2^-39 of the bound.  Non-finite inputs give non-finite outputs for their own row only (rows are MFMA columns).
+//
+// Work decomposition (what round 1's stamps asked for): 512 threads = 8 waves = two per SIMD, so the non-matrix
+// phases issue VALU at the SIMD's full rate and one wave's waits hide behind its partner's MFMAs; 128-row items, so a
+// weight fragment fetched from L2 feeds four 32-row tiles (the probe's slab loop is L2 -> CU bound at 64 rows: 489 ->
+// 680 ns per slab with the loads); every activation is split ONCE, by the wave that produced it, into two f16 images in
+// LDS which all waves read as ready MFMA operands (no VALU in the slab loop).  A 128-row h1 image would need 266 KB, so
+// layers 0 and 1 are fused over k: chunk c of h1 (64 hidden units x 128 rows, 8 (n-tile, row-tile) pairs = one per
+// wave) is produced into a double-buffered 36 KB image while the layer-1 MFMAs consume chunk c - 1.  Wave w owns hidden
+// n-tiles 2w, 2w+1 x four row tiles of layer 1 (128 accumulator registers).  h2 leaves the accumulators in two 64-row
+// halves through a [64][512] image; the output layer is split over (output tile, row tile, k half) units, its results
+// pass through an LDS staging tile so that rows are stored as contiguous runs.
+#include "common.h"
+#include "ens_mlp_internal.h"
+
+#include <stdlib.h>
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreadsH = 512;
+constexpr int kWavesH = 8;
+constexpr int HIDH = 512;
+constexpr int RT = 4;                 // 32-row tiles per item
+constexpr int ROWSH = 32 * RT;        // 128
+constexpr int NTC = 8 / RT;           // hidden n-tiles per chunk (one (n-tile, row-tile) pair per wave)
+constexpr int CK = 32 * NTC;          // hidden units per chunk
+constexpr int NCH = HIDH / CK;        // chunks
+constexpr int SLC = CK / 16;          // 16-deep slabs per chunk
+constexpr int CSTR = CK + 8;          // row stride (halves) of a chunk image: 16-B slots per row odd -> conflict-free
+constexpr int HSTR = HIDH + 8;        // row stride of the h2 image
+constexpr int NSTAT = 12;             // floats per member in the stats block: {s, L1, B, -} x 3 layers
+
+// ---- LDS map (bytes) ---------------------------------------------------------------------------------------------
+// [0, ...)            layers 0 / 1: chunk images [2][2 pieces][128][CSTR] | x image [2][128][XSTR] | W0 chunk [2][4 S0 KB]
+//                     tail:         h2 image [2 pieces][64][HSTR]  (aliases the above)  /  output staging [64][SW]
+// [OFF_PART, ...)     partial outputs of the second k half [4 units][16][64] floats
+// [OFF_CONST, ...)    bias0 | bias1 | head constants | per-row scales | input scaler
+constexpr int CBUF_BYTES = 2 * ROWSH * CSTR * 2;          // one chunk image (both pieces)
+constexpr int H2_BYTES = 2 * 64 * HSTR * 2;
+constexpr int OFF_PART = H2_BYTES;
+constexpr int PART_BYTES = 4 * 16 * 64 * 4;
+__host__ __device__ constexpr int ximg_bytes(int S0) { return 2 * ROWSH * (16 * S0 + 8) * 2; }
+__host__ __device__ constexpr int w0buf_bytes(int S0) { return NTC * S0 * 2 * 1024; }   // one chunk
+__host__ __device__ constexpr int off_const(int S0) {
+  const int a = 2 * CBUF_BYTES + ximg_bytes(S0) + 2 * w0buf_bytes(S0), b = OFF_PART + PART_BYTES;
+  return (a > b ? a : b);
+}
+constexpr int CONST_FLOATS = 2 * HIDH + 2 * 128 + 6 * ROWSH + 2 * 64;
+__host__ __device__ constexpr int lds_bytes(int S0) { return off_const(S0) + CONST_FLOATS * 4; }
+
+#ifdef CMBPO_STAMPS
+#define H3_STAMP(k)                                                         \
+  do {                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                      \
+    const unsigned long long t_now = __builtin_amdgcn_s_memtime();          \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                     \
+    t_acc[k] += t_now - t_last;                                             \
+    t_last = t_now;                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                      \
+  } while (0)
+#else
+#define H3_STAMP(k) do { } while (0)
+#endif
+
+__device__ __forceinline__ float swishf(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+// 2^k with v 2^k in [2^13, 2^14); 1 for zero, subnormal and non-finite v
+__host__ __device__ __forceinline__ float pow2_lift(float v) {
+  union { float f; unsigned u; } c;
+  c.f = v;
+  const int ex = (int)((c.u >> 23) & 255u);
+  if (ex == 0 || ex == 255) return 1.0f;
+  int k = 13 - (ex - 127);
+  k = k < -100 ? -100 : (k > 100 ? 100 : k);
+  c.u = (unsigned)(k + 127) << 23;
+  return c.f;
+}
+
+__device__ __forceinline__ void split_h(float a, _Float16 &p1, _Float16 &p2) {
+  p1 = (_Float16)a;
+  p2 = (_Float16)(a - (float)p1);   // exact difference
+}
+
+// three-term product, smallest terms first
+__device__ __forceinline__ void mm3(f32x16 &acc, const f16x8 &a1, const f16x8 &a2, const f16x8 &b1, const f16x8 &b2) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
+}
+
+// ---- per-member statistics of the fp32 packs: max |W|, largest column 1-norm, max |b| -----------------------------------
+// pack layout [n-tile][k-group][lane (r, h)][4]: W[k = 8 g + 4 h + s][n = 32 tile + r].  grid (E, 3), 512 threads.
+__global__ void h3_stats_kernel(const float *blob, size_t off0, size_t off1, size_t off2, size_t offb0, size_t offb1, size_t offb2,
+                                int kg0, int o_tiles, float *stats) {
+  const int e = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
+  const int tiles = l == 2 ? o_tiles : HIDH / 32, kg = l == 0 ? kg0 : HIDH / 8;
+  const size_t woff = l == 0 ? off0 : (l == 1 ? off1 : off2), boff = l == 0 ? offb0 : (l == 1 ? offb1 : offb2);
+  const float *w = blob + woff + (size_t)e * tiles * kg * 256;
+  const float *b = blob + boff + (size_t)e * tiles * 32;
+  float wmax = 0.0f, l1 = 0.0f, bmax = 0.0f;
+  if (tid < tiles * 32) {
+    const int tile = tid >> 5, r = tid & 31;
+    for (int g = 0; g < kg; ++g)
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(w + (((size_t)tile * kg + g) * 64 + h * 32 + r) * 4);
+        for (int s = 0; s < 4; ++s) { const float a = fabsf(v[s]); wmax = fmaxf(wmax, a); l1 += a; }
+      }
+    bmax = fabsf(b[tid]);
+  }
+  __shared__ float red[3][kThreadsH];
+  red[0][tid] = wmax; red[1][tid] = l1; red[2][tid] = bmax;
+  __syncthreads();
+  for (int st = kThreadsH / 2; st > 0; st >>= 1) {
+    if (tid < st)
+      for (int q = 0; q < 3; ++q) red[q][tid] = fmaxf(red[q][tid], red[q][tid + st]);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float *o = stats + (size_t)e * NSTAT + 4 * l;
+    o[0] = pow2_lift(red[0][0]); o[1] = red[1][0]; o[2] = red[2][0]; o[3] = red[0][0];
+  }
+}
+
+// ---- fp32 pack -> two f16 images [n-tile][k-slab 16][piece 2][lane 64][8 halves] -----------------------------------------
+// lane (r, h), element j of slab s holds W[n = 32 tile + r][k = 16 s + 8 h + j] * scale; tiles >= src_tiles and k beyond the
+// pack are zero.
+__global__ void h3_pack_kernel(const float *src, size_t src_stride, int kg, int src_tiles, f16x8 *dst, size_t dst_stride,
+                               int n_tiles, int slabs, int members, const float *stats, int layer) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per = (long)n_tiles * slabs * 64;
+  if (idx >= per * members) return;
+  const int e = (int)(idx / per);
+  const int rem = (int)(idx - (long)e * per);
+  const int lane = rem & 63, s = (rem >> 6) % slabs, tile = (rem >> 6) / slabs;
+  const int r = lane & 31, h = lane >> 5;
+  const float scale = stats[(size_t)e * NSTAT + 4 * layer];
+  const float *sp = src + (size_t)e * src_stride;
+  f16x8 p1, p2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 16 * s + 8 * h + j;
+    float v = 0.0f;
+    if (tile < src_tiles && (k >> 3) < kg) v = sp[(((size_t)tile * kg + (k >> 3)) * 64 + ((k >> 2) & 1) * 32 + r) * 4 + (k & 3)];
+    _Float16 q1, q2;
+    split_h(v * scale, q1, q2);
+    p1[j] = q1; p2[j] = q2;
+  }
+  f16x8 *d = dst + (size_t)e * dst_stride + ((size_t)tile * slabs + s) * 2 * 64 + lane;
+  d[0] = p1; d[64] = p2;
+}
+
+struct H3Args {
+  MlpKernelArgs m;
+  const f16x8 *w0, *w1, *w2;
+  size_t w0_stride, w1_stride, w2_stride;   // per member, in 16-B units
+  const float *stats;                        // [E][NSTAT]
+};
+
+template <int S0, int OTP>   // k-slabs of the input layer (in_pad <= 16 S0); output n-tiles, 2 or 4 (2 out_dim <= 32 OTP)
+__global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
+  constexpr int XSTR = 16 * S0 + 8;
+  constexpr int U = 2 * OTP;             // output units per 64-row half: (output tile, row tile)
+  constexpr int KS = 8 / U;              // k halves: 2 (OTP == 2) or 1 (OTP == 4)
+  constexpr int SPK = 32 / KS;           // slabs per unit
+  constexpr int O_PAD = 32 * OTP;
+  constexpr int W0P = NTC * S0 * 2;      // 1-KB pieces of one W0 chunk
+  constexpr int W2D = 8;                 // output-layer weight fragments in flight (slabs)
+  const MlpKernelArgs &p = a.m;
+  extern __shared__ f32x4 smem4[];
+  char *smem = reinterpret_cast<char *>(smem4);
+  _Float16 *cbuf = reinterpret_cast<_Float16 *>(smem);                               // [2][2][128][CSTR]
+  _Float16 *ximg = reinterpret_cast<_Float16 *>(smem + 2 * CBUF_BYTES);              // [2][128][XSTR]
+  f16x8 *w0buf = reinterpret_cast<f16x8 *>(smem + 2 * CBUF_BYTES + ximg_bytes(S0));   // [2][W0P][64]
+  _Float16 *h2img = reinterpret_cast<_Float16 *>(smem);                              // [2][64][HSTR]
+  float *stg = reinterpret_cast<float *>(smem);                                      // [64][SW]
+  float *part = reinterpret_cast<float *>(smem + OFF_PART);                          // [4][16][64]
+  float *cst = reinterpret_cast<float *>(smem + off_const(S0));
+  float *bias0 = cst, *bias1 = cst + HIDH, *hc_a = cst + 2 * HIDH, *hc_c = hc_a + 128;
+  int *rowidx = reinterpret_cast<int *>(hc_c + 128);
+  float *r_inv0 = reinterpret_cast<float *>(rowidx) + ROWSH, *r_t1 = r_inv0 + ROWSH, *r_inv1 = r_t1 + ROWSH,
+        *r_t2 = r_inv1 + ROWSH, *r_inv2 = r_t2 + ROWSH;
+  float *in_mu_l = r_inv2 + ROWSH, *in_sig_l = in_mu_l + 64;
+
+  const int n_rows = p.n_rows_dev ? *p.n_rows_dev : p.n_rows;
+  const int out = p.out_dim, SW = (2 * out) | 1;
+  if (threadIdx.x < 64) {   // input scaler, once per workgroup (TensorStandardScaler.transform, models/pens/utils.py:156)
+    const int k = threadIdx.x;
+    in_mu_l[k] = (p.in_mu && k < p.in_dim) ? p.in_mu[k] : 0.0f;
+    in_sig_l[k] = (p.in_mu && k < p.in_dim) ? p.in_sig[k] : 1.0f;
+  }
+  __syncthreads();
+
+  // ---- prefetch registers: the NEXT item's raw input rows, biases and output bias travel behind the current item's tail.
+  // Every load is unconditional (clamped addresses, the selection happens on the values): a load inside a per-element
+  // branch makes hipcc wait for it there, one memory round trip per element.
+  float xpre[16];
+  float bpre[2], b2pre = 0.0f;
+  int rr_pre = -1;
+  auto fetch_row = [&](int it, int tid) {
+    const int xb = tid >> 2;
+    const int e2 = it / p.tiles;
+    const int rr = (it - e2 * p.tiles) * ROWSH + xb;
+    const bool ok = it < p.n_items && rr < n_rows;
+    int v = ok ? rr : 0;
+    if (p.row_idx) v = p.row_idx[v];
+    rr_pre = ok ? v : -1;
+  };
+  auto fetch_x = [&](int tid) {
+    const int xc = tid & 3;
+    const int rr = rr_pre >= 0 ? rr_pre : 0;
+    const float *orow = p.obs + (size_t)rr * p.obs_dim;
+    const float *arow = p.act_dim > 0 ? p.act + (size_t)rr * p.act_dim - p.obs_dim : orow;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int k = 16 * xc + u;
+      const float *q = (k < p.obs_dim) ? orow + k : ((k < p.in_dim) ? arow + k : orow);
+      xpre[u] = *q;
+    }
+  };
+  auto fetch_bias = [&](int it, int tid) {
+    const int e2 = (it < p.n_items) ? it / p.tiles : 0;
+    bpre[0] = p.b0[(size_t)e2 * HIDH + tid];
+    bpre[1] = p.b1[(size_t)e2 * HIDH + tid];
+    const int ob = p.o_tiles * 32;
+    b2pre = p.b2[(size_t)e2 * ob + (tid < ob ? tid : 0)];
+  };
+  fetch_row(blockIdx.x, threadIdx.x);
+  fetch_x(threadIdx.x);
+  fetch_bias(blockIdx.x, threadIdx.x);
+#ifdef CMBPO_STAMPS
+  unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  for (int item = blockIdx.x; item < p.n_items; item += gridDim.x) {
+    // the thread index, re-read inside the loop through an opaque move: everything derived from it is recomputed per
+    // item instead of being hoisted out of the loop and parked in scratch (the loop body needs every register)
+    int tid = threadIdx.x;
+    asm volatile("v_mov_b32 %0, %0" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int xb = tid >> 2, xc = tid & 3;      // stage: row of the item, 16-wide k part
+    const int e = item / p.tiles;
+    const int row0 = (item - e * p.tiles) * ROWSH;
+    if (row0 >= n_rows) {    // (uniform) nothing alive in this tile; keep the prefetch chain going
+      fetch_row(item + gridDim.x, tid);
+      fetch_x(tid);
+      fetch_bias(item + gridDim.x, tid);
+      continue;
+    }
+    const float *st = a.stats + (size_t)e * NSTAT;
+    // ---- stage: constants, per-row scales, the split input image, the first two W0 chunks --------------------------
+    const f16x8 *w0e = a.w0 + (size_t)e * a.w0_stride;
+    {
+      f16x8 w0r[(2 * W0P + kWavesH - 1) / kWavesH];
+#pragma unroll
+      for (int u = 0; u < (2 * W0P + kWavesH - 1) / kWavesH; ++u) {
+        const int j = wave + kWavesH * u;
+        w0r[u] = w0e[(size_t)(j < 2 * W0P ? j : 0) * 64 + lane];
+      }
+      bias0[tid] = bpre[0];
+      bias1[tid] = bpre[1];
+      if (tid < O_PAD) {
+        // y = A_n z + B_n with z = o + b2_n; n < out: mean = sig z + mu; out <= n < 2 out: var = exp(z + 2 log sig)
+        // (models/pens/pe.py:815-835)
+        float A = 0.0f, Bc = 0.0f;
+        if (tid < out) { A = p.out_mu ? p.out_sig[tid] : 1.0f; Bc = p.out_mu ? p.out_mu[tid] : 0.0f; }
+        else if (tid < 2 * out) { A = 1.0f; Bc = p.out_mu ? p.out_lsig2[tid - out] : 0.0f; }
+        hc_a[tid] = A;
+        hc_c[tid] = A * b2pre + Bc;
+      }
+      float xs[16];
+      float m = 0.0f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int k = 16 * xc + u;
+        float x = (xpre[u] - in_mu_l[k & 63]) / in_sig_l[k & 63];
+        x = (k < p.in_dim && rr_pre >= 0) ? x : 0.0f;
+        xs[u] = x;
+        m = fmaxf(m, fabsf(x));
+      }
+      m = fmaxf(m, __shfl_xor(m, 1, 64));
+      m = fmaxf(m, __shfl_xor(m, 2, 64));
+      const float t0 = pow2_lift(m);
+      if (xc == 0) {
+        const float bound1 = (st[1] * m + st[2]) * 1.001f, t1 = pow2_lift(bound1);
+        const float bound2 = (st[5] * bound1 + st[6]) * 1.001f, t2 = pow2_lift(bound2);
+        rowidx[xb] = rr_pre;
+        r_inv0[xb] = 1.0f / (st[0] * t0);
+        r_t1[xb] = t1;
+        r_inv1[xb] = 1.0f / (st[4] * t1);
+        r_t2[xb] = t2;
+        r_inv2[xb] = 1.0f / (st[8] * t2);
+      }
+      if (xc < S0) {
+        f16x8 q1[2], q2[2];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          _Float16 c1, c2;
+          split_h(xs[u] * t0, c1, c2);
+          q1[u >> 3][u & 7] = c1; q2[u >> 3][u & 7] = c2;
+        }
+        f16x8 *d1 = reinterpret_cast<f16x8 *>(ximg + (size_t)xb * XSTR + 16 * xc);
+        f16x8 *d2 = reinterpret_cast<f16x8 *>(ximg + (size_t)(ROWSH + xb) * XSTR + 16 * xc);
+        d1[0] = q1[0]; d1[1] = q1[1]; d2[0] = q2[0]; d2[1] = q2[1];
+      }
+#pragma unroll
+      for (int u = 0; u < (2 * W0P + kWavesH - 1) / kWavesH; ++u) {
+        const int j = wave + kWavesH * u;
+        if (j < 2 * W0P) w0buf[(size_t)j * 64 + lane] = w0r[u];     // chunks 0, 1
+      }
+    }
+    fetch_row(item + gridDim.x, tid);     // the next item's row index: lands during the layers
+    H3_STAMP(0);
+    __syncthreads();
+    H3_STAMP(1);
+
+    // ---- layers 0 + 1, fused over the 8 chunks of h1 -------------------------------------------------------------------
+    const int l0_tn = wave & (NTC - 1), l0_bt = wave / NTC;     // this wave's (n-tile, row-tile) pair of every chunk
+    const float inv0_l = r_inv0[32 * l0_bt + r], t1_l = r_t1[32 * l0_bt + r];
+    auto layer0_chunk = [&](int cc) {
+      f32x16 d;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) d[i] = 0.0f;
+      const f16x8 *wa = w0buf + ((size_t)(cc & 1) * W0P + (size_t)l0_tn * S0 * 2) * 64 + lane;
+      const _Float16 *xb0 = ximg + (size_t)(32 * l0_bt + r) * XSTR + 8 * hh;
+#pragma unroll
+      for (int s = 0; s < S0; ++s) {
+        const f16x8 a1 = wa[(size_t)(2 * s) * 64], a2 = wa[(size_t)(2 * s + 1) * 64];
+        const f16x8 b1 = *reinterpret_cast<const f16x8 *>(xb0 + 16 * s);
+        const f16x8 b2 = *reinterpret_cast<const f16x8 *>(xb0 + (size_t)ROWSH * XSTR + 16 * s);
+        mm3(d, a1, a2, b1, b2);
+      }
+      _Float16 *c1 = cbuf + (size_t)(cc & 1) * (CBUF_BYTES / 2) + (size_t)(32 * l0_bt + r) * CSTR + 32 * l0_tn + 4 * hh;
+      _Float16 *c2 = c1 + (size_t)ROWSH * CSTR;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias0 + cc * CK + 32 * l0_tn + 8 * q + 4 * hh);
+        f16x4 o1, o2;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float z = d[4 * q + s] * inv0_l + bv[s];
+          _Float16 e1, e2;
+          split_h(swishf(z) * t1_l, e1, e2);
+          o1[s] = e1; o2[s] = e2;
+        }
+        *reinterpret_cast<f16x4 *>(c1 + 8 * q) = o1;
+        *reinterpret_cast<f16x4 *>(c2 + 8 * q) = o2;
+      }
+    };
+
+    f32x16 acc[2][RT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int bt = 0; bt < RT; ++bt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][bt][i] = 0.0f;
+    const f16x8 *w1a = a.w1 + (size_t)e * a.w1_stride + (size_t)(2 * wave) * 32 * 128 + lane;   // [tile][slab 32][piece][lane]
+    f16x8 A[2][2][2];      // [ping-pong][n-tile][piece]
+    f16x8 Bg[2][2][2];     // [row-tile pair][row tile][piece]
+    auto load_a = [&](f16x8 (&x)[2][2], int s) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f16x8 *q = w1a + ((size_t)t * 32 + s) * 128;
+        x[t][0] = q[0]; x[t][1] = q[64];
+      }
+    };
+    auto read_b = [&](f16x8 (&x)[2][2], const _Float16 *img, int g, int sl) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const _Float16 *q = img + (size_t)(32 * (2 * g + b) + r) * CSTR + 16 * sl + 8 * hh;
+        x[b][0] = *reinterpret_cast<const f16x8 *>(q);
+        x[b][1] = *reinterpret_cast<const f16x8 *>(q + (size_t)ROWSH * CSTR);
+      }
+    };
+    load_a(A[0], 0);
+    layer0_chunk(0);
+    __syncthreads();
+    H3_STAMP(2);
+
+    // The two waves of a SIMD run the step's halves in opposite order: waves 0-3 produce chunk c + 1 (LDS reads, 9 MFMAs,
+    // swish / split VALU, LDS writes) and then run the layer-1 slabs of chunk c, waves 4-7 run the slabs first -- one
+    // wave's non-matrix work stands beside its partner's MFMAs instead of beside its partner's non-matrix work.
+    const bool late = wave >= kWavesH / 2;
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+      f16x8 wst[2];
+      const bool stage_w0 = c + 2 < NCH;
+      if (stage_w0) {   // W0 fragments of chunk c + 2: requested now, written to LDS at the end of the step
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int j = wave + kWavesH * u;
+          wst[u] = w0e[((size_t)(c + 2) * W0P + (j < W0P ? j : 0)) * 64 + lane];
+        }
+      }
+      if (!late && c + 1 < NCH) layer0_chunk(c + 1);
+      H3_STAMP(3);
+      const _Float16 *img = cbuf + (size_t)(c & 1) * (CBUF_BYTES / 2);
+      read_b(Bg[0], img, 0, 0);
+#pragma unroll
+      for (int sl = 0; sl < SLC; ++sl) {
+        const int s = c * SLC + sl;
+        f16x8(&Ac)[2][2] = A[sl & 1];
+        f16x8(&An)[2][2] = A[(sl & 1) ^ 1];
+        load_a(An, s + 1 < 32 ? s + 1 : s);
+        read_b(Bg[1], img, 1, sl);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) mm3(acc[t][b], Ac[t][0], Ac[t][1], Bg[0][b][0], Bg[0][b][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (sl + 1 < SLC) read_b(Bg[0], img, 0, sl + 1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) mm3(acc[t][2 + b], Ac[t][0], Ac[t][1], Bg[1][b][0], Bg[1][b][1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      H3_STAMP(4);
+      if (late && c + 1 < NCH) layer0_chunk(c + 1);
+      if (stage_w0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int j = wave + kWavesH * u;
+          if (j < W0P) w0buf[((size_t)(c & 1) * W0P + j) * 64 + lane] = wst[u];
+        }
+      }
+      __syncthreads();
+      H3_STAMP(5);
+    }
+
+    // the next item's rows, biases and output bias: in flight behind the tail
+    fetch_x(tid);
+    fetch_bias(item + gridDim.x, tid);
+    H3_STAMP(6);
+
+    // ---- tail: h2 -> output layer -> head -> stores, one 64-row half at a time ---------------------------------------
+    const int u_id = wave % U, ks = wave / U;                      // (KS == 1: ks == 0 for every wave)
+    const int t2i = u_id >> 1, btl = u_id & 1;
+    const f16x8 *wq = a.w2 + (size_t)e * a.w2_stride + lane + ((size_t)t2i * 32 + (size_t)ks * SPK) * 128;   // [tile][slab][piece][lane]
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      // the first output-layer weight fragments: requested ahead of the epilogue that hides their latency
+      f16x8 wa[W2D][2];
+#pragma unroll
+      for (int d = 0; d < W2D; ++d) { wa[d][0] = wq[(size_t)d * 128]; wa[d][1] = wq[(size_t)d * 128 + 64]; }
+      // (a) this half of h2: swish, lift, split, image
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int rowi = 32 * (2 * hf + b) + r;
+        const float inv1_l = r_inv1[rowi], t2_l = r_t2[rowi];
+        _Float16 *c1 = h2img + (size_t)(32 * b + r) * HSTR + 64 * wave + 4 * hh;
+        _Float16 *c2 = c1 + (size_t)64 * HSTR;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias1 + 64 * wave + 32 * t + 8 * q + 4 * hh);
+            f16x4 o1, o2;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const float z = acc[t][2 * hf + b][4 * q + s] * inv1_l + bv[s];
+              _Float16 e1, e2;
+              split_h(swishf(z) * t2_l, e1, e2);
+              o1[s] = e1; o2[s] = e2;
+            }
+            *reinterpret_cast<f16x4 *>(c1 + 32 * t + 8 * q) = o1;
+            *reinterpret_cast<f16x4 *>(c2 + 32 * t + 8 * q) = o2;
+          }
+      }
+      H3_STAMP(7);
+      __syncthreads();
+      // (b) output layer: unit (t2i, btl), slabs [ks SPK, (ks + 1) SPK)
+      f32x16 o;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[i] = 0.0f;
+      {
+        const _Float16 *hq = h2img + (size_t)(32 * btl + r) * HSTR + 16 * ks * SPK + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < SPK; ++s) {
+          const f16x8 b1 = *reinterpret_cast<const f16x8 *>(hq + 16 * s);
+          const f16x8 b2 = *reinterpret_cast<const f16x8 *>(hq + (size_t)64 * HSTR + 16 * s);
+          mm3(o, wa[s % W2D][0], wa[s % W2D][1], b1, b2);
+          if (s + W2D < SPK) {
+            wa[s % W2D][0] = wq[(size_t)(s + W2D) * 128];
+            wa[s % W2D][1] = wq[(size_t)(s + W2D) * 128 + 64];
+          }
+        }
+      }
+      if (KS == 2 && ks == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[(u_id * 16 + i) * 64 + lane] = o[i];
+      }
+      H3_STAMP(8);
+      __syncthreads();     // every read of the h2 image is done: the region becomes the output staging tile
+      // (c) head (models/pens/pe.py:815-835): mean = sig (o + b2) + mu ; var = exp(2 log sig + o' + b2')
+      if (ks == 0) {
+        const float inv2_l = r_inv2[32 * (2 * hf + btl) + r];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int n = 32 * t2i + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          float v = o[i];
+          if (KS == 2) v += part[(u_id * 16 + i) * 64 + lane];
+          float y = hc_a[n] * (v * inv2_l) + hc_c[n];
+          if (n >= out) y = __expf(y);
+          if (n < 2 * out) stg[(32 * btl + r) * SW + n] = y;
+        }
+      }
+      H3_STAMP(9);
+      __syncthreads();
+      // (d) stores: a row's means / variances are contiguous runs of `out` floats
+#pragma unroll 1
+      for (int j = 0; j < 8; ++j) {
+        const int rl = wave + kWavesH * j;                 // row of this half
+        const int rr = rowidx[64 * hf + rl];
+        if (rr >= 0) {
+          const size_t obase = ((size_t)e * p.ld_rows + rr) * out;
+          for (int n = lane; n < 2 * out; n += 64) {
+            const float y = stg[rl * SW + n];
+            if (n < out) p.out0[obase + n] = y;
+            else p.out1[obase + (n - out)] = y;
+          }
+        }
+      }
+      H3_STAMP(10);
+      __syncthreads();     // the staging tile is overwritten by the next half's image / the next item's stage
+      H3_STAMP(11);
+    }
+  }  // persistent item loop
+#ifdef CMBPO_STAMPS
+  if (p.stamps && threadIdx.x == 0) {
+    for (int k = 0; k < 12; ++k) p.stamps[(size_t)blockIdx.x * 16 + k] = t_acc[k];
+    p.stamps[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memrealtime() - t_rt0;
+  }
+#endif
+}
+
+}  // namespace
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+// (re)builds the statistics and the two f16 images from the handle's fp32 packs when they changed since the last build
+static int ensure_h3(cmbpo_mlp *m, hipStream_t s) {
+  const int H = m->hidden, E = m->ensemble;
+  const int S0 = m->h3_s0, OTP = m->h3_otp;
+  const int slabs[3] = {S0, H / 16, H / 16};
+  const int tiles[3] = {H / 32, H / 32, OTP};
+  if (m->d_h3 == nullptr) {
+    size_t off = 0;
+    for (int l = 0; l < 3; ++l) {
+      m->h3_stride[l] = (size_t)tiles[l] * slabs[l] * 2 * 64;
+      m->h3_off[l] = off;
+      off += m->h3_stride[l] * E;
+    }
+    m->h3_stats_off = off;    // in 16-B units
+    const size_t bytes = off * 16 + (size_t)E * NSTAT * sizeof(float);
+    if (hipMalloc(&m->d_h3, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      m->d_h3 = nullptr;
+      cmbpo_set_error("ens_h3: hipMalloc of the f16 weight images failed");
+      return CMBPO_ENOMEM;
+    }
+    m->h3_version = ~0ul;
+  }
+  if (m->h3_version == m->pack_version) return CMBPO_OK;
+  float *stats = reinterpret_cast<float *>(reinterpret_cast<char *>(m->d_h3) + m->h3_stats_off * 16);
+  hipLaunchKernelGGL(h3_stats_kernel, dim3(E, 3), dim3(kThreadsH), 0, s, m->d_blob, m->off_wp0, m->off_wp1, m->off_wp2,
+                     m->off_b0, m->off_b1, m->off_b2, m->in_pad / 8, m->o_tiles, stats);
+  const size_t src_off[3] = {m->off_wp0, m->off_wp1, m->off_wp2};
+  const int kg[3] = {m->in_pad / 8, H / 8, H / 8};
+  const int src_tiles[3] = {H / 32, H / 32, m->o_tiles};
+  for (int l = 0; l < 3; ++l) {
+    const size_t src_stride = (size_t)src_tiles[l] * kg[l] * 256;
+    const long total = (long)tiles[l] * slabs[l] * 64 * E;
+    hipLaunchKernelGGL(h3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, m->d_blob + src_off[l], src_stride,
+                       kg[l], src_tiles[l], reinterpret_cast<f16x8 *>(m->d_h3) + m->h3_off[l], m->h3_stride[l], tiles[l], slabs[l],
+                       E, stats, l);
+  }
+  CMBPO_HIP_CHECK(hipGetLastError());
+  m->h3_version = m->pack_version;
+  return CMBPO_OK;
+}
+
+bool cmbpo_internal_h3_eligible(const cmbpo_mlp *m) {
+  return m->head == CMBPO_HEAD_PROB && m->hidden == 512 && m->act == CMBPO_ACT_SWISH && m->o_tiles <= 4 && m->in_pad <= 64 &&
+         2 * m->out_dim == m->o_width;
+}
+
+int cmbpo_internal_launch_h3(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
+  if (m->h3_s0 == 0) {
+    const int s0 = (m->in_pad + 15) / 16;
+    m->h3_s0 = s0 < 2 ? 2 : s0;
+    m->h3_otp = m->o_tiles <= 2 ? 2 : 4;
+  }
+  if (int rc = ensure_h3(m, s)) return rc;
+  H3Args k{};
+  k.m = a;
+  const f16x8 *base = reinterpret_cast<const f16x8 *>(m->d_h3);
+  k.w0 = base + m->h3_off[0]; k.w1 = base + m->h3_off[1]; k.w2 = base + m->h3_off[2];
+  k.w0_stride = m->h3_stride[0]; k.w1_stride = m->h3_stride[1]; k.w2_stride = m->h3_stride[2];
+  k.stats = reinterpret_cast<const float *>(reinterpret_cast<const char *>(m->d_h3) + m->h3_stats_off * 16);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  const int tiles = cmbpo_ceil_div(a.n_rows, ROWSH);
+  k.m.tiles = tiles;
+  k.m.n_items = tiles * m->ensemble;
+  const int S0 = m->h3_s0, OTP = m->h3_otp;
+  const size_t lds = (size_t)lds_bytes(S0);
+  CMBPO_REQUIRE(lds <= 160 * 1024, "ens_h3: LDS budget exceeded (%zu B)", lds);
+  CMBPO_REQUIRE((size_t)64 * ((2 * m->out_dim) | 1) * 4 <= (size_t)OFF_PART, "ens_h3: staging tile does not fit");
+  const int grid = k.m.n_items < n_cu ? k.m.n_items : n_cu;
+  static size_t attr_done[5][5] = {};
+#define CMBPO_H3_CASE(S0_, OTP_)                                                                                       \
+  if (S0 == S0_ && OTP == OTP_) {                                                                                      \
+    if (!attr_done[S0_][OTP_]) {                                                                                       \
+      CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ens_h3_kernel<S0_, OTP_>),                    \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
+      attr_done[S0_][OTP_] = 1;                                                                                        \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((ens_h3_kernel<S0_, OTP_>), dim3(grid), dim3(kThreadsH), lds, s, k);                           \
+  }
+  CMBPO_H3_CASE(2, 2) CMBPO_H3_CASE(3, 2) CMBPO_H3_CASE(4, 2) CMBPO_H3_CASE(2, 4) CMBPO_H3_CASE(3, 4) CMBPO_H3_CASE(4, 4)
+#undef CMBPO_H3_CASE
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}

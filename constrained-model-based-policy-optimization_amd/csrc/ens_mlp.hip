@@ -597,6 +597,7 @@ extern "C" void cmbpo_mlp_destroy(cmbpo_mlp_t *m) {
   if (!m) return;
   if (m->d_blob) (void)hipFree(m->d_blob);
   if (m->d_split) (void)hipFree(m->d_split);
+  if (m->d_h3) (void)hipFree(m->d_h3);
   delete m;
 }
 
@@ -703,7 +704,9 @@ int launch_one(MlpKernelArgs &a, int tiles, int chunks, size_t lds, hipStream_t 
 }
 
 int g_block_rows = 32;  // 32 (2 workgroups / CU) or 64 (1 workgroup / CU)
-int g_split_path = getenv("CMBPO_ENS_SPLIT") ? (atoi(getenv("CMBPO_ENS_SPLIT")) != 0) : 1;   // 1: ens_split.hip for the 512-wide PROB forward
+// matrix path of the 512-wide PROB forward: 0 fp32 MFMAs, 1 ens_split.hip (six bf16 terms), 2 ens_h3.hip (three f16 terms)
+int g_split_path = getenv("CMBPO_ENS_SPLIT") ? atoi(getenv("CMBPO_ENS_SPLIT")) : CMBPO_ENS_SPLIT_F16;
+int g_h3_min_rows = getenv("CMBPO_ENS_H3_MIN_ROWS") ? atoi(getenv("CMBPO_ENS_H3_MIN_ROWS")) : 0;
 int g_stagger = 10;     // x s_sleep(127) (~8k cycles each) for the second dispatch batch
 int g_lds_pad = 0;      // diagnostic: extra dynamic LDS bytes (forces one workgroup per CU)
 
@@ -734,6 +737,8 @@ int launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s, int head_override 
   a.o_width = m->o_width; a.o_tiles = m->o_tiles; a.out_dim = m->out_dim;
   if (a.n_rows <= 0) return CMBPO_OK;
 
+  if (g_split_path == CMBPO_ENS_SPLIT_F16 && head == CMBPO_HEAD_PROB && cmbpo_internal_h3_eligible(m) && a.n_rows >= g_h3_min_rows)
+    return cmbpo_internal_launch_h3(m, a, s);
   if (head == CMBPO_HEAD_PROB && H == 512 && m->act == CMBPO_ACT_SWISH && m->o_tiles <= 4 && m->in_pad <= 64 && g_split_path)
     return cmbpo_internal_launch_split(m, a, s);
   // (the critics' split kernel pays from ~30 k rows: below that a launch is one round of items and an item's latency
@@ -778,8 +783,15 @@ int cmbpo_internal_launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s, int
 }
 
 extern "C" int cmbpo_set_ens_matrix_path(int path) {
-  CMBPO_REQUIRE(path == CMBPO_ENS_FP32 || path == CMBPO_ENS_SPLIT_BF16, "cmbpo_set_ens_matrix_path: 0 (fp32 MFMA) or 1 (split bf16)");
+  CMBPO_REQUIRE(path == CMBPO_ENS_FP32 || path == CMBPO_ENS_SPLIT_BF16 || path == CMBPO_ENS_SPLIT_F16,
+                "cmbpo_set_ens_matrix_path: 0 (fp32 MFMA), 1 (six bf16 terms) or 2 (three f16 terms)");
   g_split_path = path;
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_set_ens_f16_min_rows(int rows) {
+  CMBPO_REQUIRE(rows >= 0, "cmbpo_set_ens_f16_min_rows: rows >= 0");
+  g_h3_min_rows = rows;
   return CMBPO_OK;
 }
 

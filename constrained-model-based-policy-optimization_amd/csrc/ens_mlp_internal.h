@@ -60,6 +60,11 @@ struct cmbpo_mlp {
   void *d_split = nullptr;
   unsigned long pack_version = 0, split_version = ~0ul;
   size_t sp_off[3] = {0, 0, 0}, sp_stride[3] = {0, 0, 0};   // 16-B units
+  // three-term f16 forward (ens_h3.hip): two f16 images of the packed weights + per-member statistics
+  void *d_h3 = nullptr;
+  unsigned long h3_version = ~0ul;
+  size_t h3_off[3] = {0, 0, 0}, h3_stride[3] = {0, 0, 0}, h3_stats_off = 0;   // 16-B units
+  int h3_s0 = 0, h3_otp = 0;   // k-slabs of the input layer, padded output tiles
 };
 
 // fills the weight / scaler pointers of `a` from the handle and launches the kernel matching (hidden, act, head);
@@ -68,5 +73,8 @@ int cmbpo_internal_launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s, int
 // HEAD_PROB, 512-wide, swish: the same forward on the bf16 matrix cores (fp32 products as six bf16 MFMAs); `a` filled
 // as for cmbpo_internal_launch_mlp
 int cmbpo_internal_launch_split(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s);
+// HEAD_PROB, 512-wide, swish: the same forward with three f16 MFMAs per float32 product, 128-row items (ens_h3.hip)
+bool cmbpo_internal_h3_eligible(const cmbpo_mlp *m);
+int cmbpo_internal_launch_h3(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s);
 // HEAD_DETMEAN, 128-wide, swish, one output (the critics) on the same matrix path
 int cmbpo_internal_launch_critic_split(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s);

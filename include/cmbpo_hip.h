@@ -68,12 +68,22 @@ int cmbpo_set_dispatch_mode(int mode);
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- every partial product exact, dropped terms <= 2^-24 |ab|,
  * measured error 6.2e-7 of sum|a_k b_k| at K = 512 against 7.6e-7 for the fp32 MFMA chain
  * (tools/split_bf16_probe.hip) -- at about twice the matrix rate.  Both pass the same parity tests.  The
- * environment variable CMBPO_ENS_SPLIT=0/1 sets the initial value.  The switch also covers the critics
- * (cmbpo_ens_predict_mean at 128 hidden units, one output); every other shape / head uses fp32 MFMAs. */
+ * environment variable CMBPO_ENS_SPLIT=0/1/2 sets the initial value.  The switch also covers the critics
+ * (cmbpo_ens_predict_mean at 128 hidden units, one output; paths 1 and 2 both mean the bf16 split there); every other
+ * shape / head uses fp32 MFMAs.
+ * CMBPO_ENS_SPLIT_F16 (default since round 2, csrc/ens_h3.hip): every operand is lifted by a power of two into the top
+ * of the f16 range and split exactly into two f16 pieces (11 + 1 + 11 significant bits = a float32 rounding);
+ * a.b = a2 b1 + a1 b2 + a1 b1 runs as three v_mfma_f32_32x32x16_f16 with fp32 accumulation -- measured error 3.2e-7 of
+ * sum|a_k b_k| at K = 512 (tools/split_f16_probe.hip) -- with scales derived from norm bounds so that no finite input
+ * can overflow a piece.  Rows of a call below cmbpo_set_ens_f16_min_rows take the bf16 path (smaller items). */
 #define CMBPO_ENS_FP32 0
 #define CMBPO_ENS_SPLIT_BF16 1
+#define CMBPO_ENS_SPLIT_F16 2
 int cmbpo_set_ens_matrix_path(int path);
 int cmbpo_get_ens_matrix_path(void);
+/* Tuning knob: calls of the 512-wide probabilistic forward with fewer rows than this use CMBPO_ENS_SPLIT_BF16 even when
+ * CMBPO_ENS_SPLIT_F16 is selected (its 128-row items leave CUs idle at small rollout batches); 0 = never. */
+int cmbpo_set_ens_f16_min_rows(int rows);
 
 /* ------------------------------------------------------------------------ *
  * Ensemble MLP handle: a 3-layer (in -> H -> H -> O) ensemble of E members.

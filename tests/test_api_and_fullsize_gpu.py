@@ -137,11 +137,7 @@ def test_rollout_properties_at_bench_size(hip_lib):
     from cmbpo_amd import synthetic
     task, B, T = "AntSafe-v2", 100000, 7
     w = bench.build_world(0, task)
-    bench.MAXROLL = T
-    try:
-        sampler, pool, env, policy = bench.build_hip(w, task, B, torch.device("cuda:0"))
-    finally:
-        bench.MAXROLL = 35
+    sampler, pool, env, policy = bench.build_hip(w, task, B, torch.device("cuda:0"), maxroll=T)
     rng = np.random.default_rng(5)
     start = synthetic.start_states(rng, B, task)
     sampler.reset(torch.from_numpy(start).cuda())

@@ -38,7 +38,7 @@ def _dyn_model(rng, task, hidden=512, E=7):
     return m, ws, bs, sc_in, sc_out, obs_dim, act_dim
 
 
-@pytest.mark.parametrize("ens_path", [0, 1], indirect=True, ids=["fp32mfma", "splitbf16"])
+@pytest.mark.parametrize("ens_path", [0, 1, 2], indirect=True, ids=["fp32mfma", "splitbf16", "splitf16"])
 @pytest.mark.parametrize("task", ["AntSafe-v2", "HalfCheetahSafe-v2", "HopperSafe-v2", "HumanoidSafe-v2"])
 @pytest.mark.parametrize("n", [1, 31, 32, 33, 63, 64, 65, 257, 1200, 2431])   # more than 36 tiles of 32 rows x 7 members: 64-row items
 def test_ens_forward_matches_oracle(hip_lib, ens_path, task, n):
@@ -89,7 +89,7 @@ def test_ens_forward_row_gather_and_split_inputs(hip_lib):
     assert np.isnan(got[:, untouched]).all()     # rows outside the list are never written
 
 
-@pytest.mark.parametrize("ens_path", [0, 1], indirect=True, ids=["fp32mfma", "splitbf16"])
+@pytest.mark.parametrize("ens_path", [0, 1, 2], indirect=True, ids=["fp32mfma", "splitbf16", "splitf16"])
 @pytest.mark.parametrize("obs_dim", [29, 45, 11])
 @pytest.mark.parametrize("n", [1, 32, 63, 65, 100, 1000, 32768 + 37])    # from 32768 rows: the split path's own kernel
 def test_critic_predict_mean(hip_lib, ens_path, n, obs_dim):
@@ -240,8 +240,8 @@ def test_fake_env_step_end_to_end(hip_lib):
 
 
 def test_ens_matrix_paths_agree_and_follow_weight_updates(hip_lib):
-    """The two matrix paths of the 512-wide forward differ by float32 rounding only (far inside the parity tolerance),
-    and the split path's bf16 weight images follow every change of the weights."""
+    """The three matrix paths of the 512-wide forward differ by float32 rounding only (far inside the parity tolerance),
+    and the split paths' bf16 / f16 weight images follow every change of the weights."""
     _cuda()
     rng = np.random.default_rng(77)
     m, ws, bs, sc_in, sc_out, obs_dim, act_dim = _dyn_model(rng, "AntSafe-v2")
@@ -249,18 +249,19 @@ def test_ens_matrix_paths_agree_and_follow_weight_updates(hip_lib):
     out = {}
     before = hip_lib.cmbpo_get_ens_matrix_path()
     try:
-        for path in (0, 1):
+        for path in (0, 1, 2):
             assert hip_lib.cmbpo_set_ens_matrix_path(path) == 0
             out[path] = m.predict_ensemble(x)
         scale = float(np.abs(out[0][0]).max())
-        assert float(np.abs(out[0][0] - out[1][0]).max()) <= 2e-5 * scale
-        np.testing.assert_allclose(out[1][1], out[0][1], rtol=2e-4)
-        assert float(np.abs(out[0][0] - out[1][0]).max()) > 0.0          # they ARE different instruction streams
+        for path in (1, 2):
+            assert float(np.abs(out[0][0] - out[path][0]).max()) <= 2e-5 * scale
+            np.testing.assert_allclose(out[path][1], out[0][1], rtol=2e-4)
+            assert float(np.abs(out[0][0] - out[path][0]).max()) > 0.0          # they ARE different instruction streams
         # new weights: both paths must see them
         ws2 = [(w * 1.1).astype(np.float32) for w in ws]
         m.set_weights(ws2, bs, sc_in, sc_out)
         ref = refcpu.ens_forward(x[:64], ws2, bs, sc_in, sc_out)
-        for path in (0, 1):
+        for path in (0, 1, 2):
             hip_lib.cmbpo_set_ens_matrix_path(path)
             mean, var = m.predict_ensemble(x[:64])
             np.testing.assert_allclose(mean, ref[0], rtol=2e-4, atol=2e-4)

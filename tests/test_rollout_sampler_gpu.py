@@ -68,7 +68,7 @@ def _need_gpu():
 
 @pytest.mark.parametrize("name", ["g5_trace_ant_unc", "g5_trace_ant_term", "g5_trace_hcs_sched",
                                   "g5_trace_hopper_budget", "g5_trace_humanoid_512"])
-@pytest.mark.parametrize("ens_path", [0, 1], indirect=True, ids=["fp32mfma", "splitbf16"])
+@pytest.mark.parametrize("ens_path", [0, 1, 2], indirect=True, ids=["fp32mfma", "splitbf16", "splitf16"])
 def test_hip_sampler_reproduces_reference_trace(hip_lib, ens_path, name):
     _need_gpu()
     from worlds import build_world

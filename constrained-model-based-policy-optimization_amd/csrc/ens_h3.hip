@@ -39,6 +39,7 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreadsH = 512;
 constexpr int kWavesH = 8;
@@ -50,23 +51,21 @@ constexpr int CK = 32 * NTC;          // hidden units per chunk
 constexpr int NCH = HIDH / CK;        // chunks
 constexpr int SLC = CK / 16;          // 16-deep slabs per chunk
 constexpr int CSTR = CK + 8;          // row stride (halves) of a chunk image: 16-B slots per row odd -> conflict-free
-constexpr int HSTR = HIDH + 8;        // row stride of the h2 image
 constexpr int NSTAT = 12;             // floats per member in the stats block: {s, L1, B, -} x 3 layers
 
 // ---- LDS map (bytes) ---------------------------------------------------------------------------------------------
 // [0, ...)            layers 0 / 1: chunk images [2][2 pieces][128][CSTR] | x image [2][128][XSTR] | W0 chunk [2][4 S0 KB]
-//                     tail:         h2 image [2 pieces][64][HSTR]  (aliases the above)  /  output staging [64][SW]
-// [OFF_PART, ...)     partial outputs of the second k half [4 units][16][64] floats
+//                     tail (aliases the above): partial outputs [2][8 waves][2 tiles][16][64] f32 | staging [2][32][SWS]
 // [OFF_CONST, ...)    bias0 | bias1 | head constants | per-row scales | input scaler
 constexpr int CBUF_BYTES = 2 * ROWSH * CSTR * 2;          // one chunk image (both pieces)
-constexpr int H2_BYTES = 2 * 64 * HSTR * 2;
-constexpr int OFF_PART = H2_BYTES;
-constexpr int PART_BYTES = 4 * 16 * 64 * 4;
+constexpr int PBUF_BYTES = kWavesH * 2 * 16 * 64 * 4;     // partial outputs of one unit: [8 waves][2 tiles][4][64 lanes] x 16 B
+constexpr int SWS = 65;                                   // row stride of a staging tile (floats): odd
+constexpr int STG_BYTES = 32 * SWS * 4;
 __host__ __device__ constexpr int ximg_bytes(int S0) { return 2 * ROWSH * (16 * S0 + 8) * 2; }
 __host__ __device__ constexpr int w0buf_bytes(int S0) { return NTC * S0 * 2 * 1024; }   // one chunk
 __host__ __device__ constexpr int off_const(int S0) {
-  const int a = 2 * CBUF_BYTES + ximg_bytes(S0) + 2 * w0buf_bytes(S0), b = OFF_PART + PART_BYTES;
-  return (a > b ? a : b);
+  const int a = 2 * CBUF_BYTES + ximg_bytes(S0) + 2 * w0buf_bytes(S0), b = 2 * PBUF_BYTES + 2 * STG_BYTES;
+  return ((a > b ? a : b) + 15) / 16 * 16;
 }
 constexpr int CONST_FLOATS = 2 * HIDH + 2 * 128 + 6 * ROWSH + 2 * 64;
 __host__ __device__ constexpr int lds_bytes(int S0) { return off_const(S0) + CONST_FLOATS * 4; }
@@ -146,9 +145,11 @@ __global__ void h3_stats_kernel(const float *blob, size_t off0, size_t off1, siz
 
 // ---- fp32 pack -> two f16 images [n-tile][k-slab 16][piece 2][lane 64][8 halves] -----------------------------------------
 // lane (r, h), element j of slab s holds W[n = 32 tile + r][k = 16 s + 8 h + j] * scale; tiles >= src_tiles and k beyond the
-// pack are zero.
+// pack are zero.  perm (output layer: its B operand is an accumulator tile, whose register i of lane half h is hidden
+// unit (i & 3) + 8 (i >> 2) + 4 h of the tile): slab s covers registers 8 (s & 1) .. + 7 of hidden n-tile s >> 1, i.e.
+// k = 32 (s >> 1) + (i & 3) + 8 (i >> 2) + 4 h with i = 8 (s & 1) + j.
 __global__ void h3_pack_kernel(const float *src, size_t src_stride, int kg, int src_tiles, f16x8 *dst, size_t dst_stride,
-                               int n_tiles, int slabs, int members, const float *stats, int layer) {
+                               int n_tiles, int slabs, int members, const float *stats, int layer, int perm) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long per = (long)n_tiles * slabs * 64;
   if (idx >= per * members) return;
@@ -161,7 +162,11 @@ __global__ void h3_pack_kernel(const float *src, size_t src_stride, int kg, int 
   f16x8 p1, p2;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int k = 16 * s + 8 * h + j;
+    int k = 16 * s + 8 * h + j;
+    if (perm) {
+      const int i = 8 * (s & 1) + j;
+      k = 32 * (s >> 1) + (i & 3) + 8 * (i >> 2) + 4 * h;
+    }
     float v = 0.0f;
     if (tile < src_tiles && (k >> 3) < kg) v = sp[(((size_t)tile * kg + (k >> 3)) * 64 + ((k >> 2) & 1) * 32 + r) * 4 + (k & 3)];
     _Float16 q1, q2;
@@ -179,24 +184,81 @@ struct H3Args {
   const float *stats;                        // [E][NSTAT]
 };
 
+// ---- the swish / lift / split epilogue of four accumulator values, cut into twelve pieces of at most ~20 issue cycles
+// so that one piece can stand behind each MFMA of a 12-MFMA group (a wave issues in order: what stands between two MFMAs
+// runs in the shadow of the first).  The split uses the mixed-precision FMAs: p1 = f16(x t) and p2 = f16(x t - p1) are
+// one v_fma_mix{lo,hi}_f16 each -- the product is exact inside the FMA, so p1 + p2 = x t (1 + d), |d| <= 2^-24, with a
+// single rounding per piece -- and lo / hi write the two halves of a dword, so the pieces come out packed.
+// PIN: an empty volatile asm after each piece keeps the compiler from sinking it into a later piece.
+struct Epi4 {
+  float z[4], e[4];
+  unsigned q1[2], q2[2];   // p1 / p2 of the four values, packed f16x2
+};
+template <int K, bool PIN>
+__device__ __forceinline__ void epi_stage(Epi4 &s, const f32x16 &d, int q, float inv, const f32x4 &bv, float tn) {
+  if constexpr (K == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.z[i] = __builtin_fmaf(d[4 * q + i], inv, bv[i]);
+    if (PIN) asm volatile("" : "+v"(s.z[0]), "+v"(s.z[1]), "+v"(s.z[2]), "+v"(s.z[3]));
+  } else if constexpr (K == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.e[i] = s.z[i] * -1.4426950408889634f;
+    if (PIN) asm volatile("" : "+v"(s.e[0]), "+v"(s.e[1]), "+v"(s.e[2]), "+v"(s.e[3]));
+  } else if constexpr (K == 2 || K == 3) {
+    constexpr int o = 2 * (K - 2);
+    s.e[o] = __builtin_amdgcn_exp2f(s.e[o]); s.e[o + 1] = __builtin_amdgcn_exp2f(s.e[o + 1]);
+    if (PIN) asm volatile("" : "+v"(s.e[o]), "+v"(s.e[o + 1]));
+  } else if constexpr (K == 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.e[i] = 1.0f + s.e[i];
+    if (PIN) asm volatile("" : "+v"(s.e[0]), "+v"(s.e[1]), "+v"(s.e[2]), "+v"(s.e[3]));
+  } else if constexpr (K == 5 || K == 6) {
+    constexpr int o = 2 * (K - 5);
+    s.e[o] = __builtin_amdgcn_rcpf(s.e[o]); s.e[o + 1] = __builtin_amdgcn_rcpf(s.e[o + 1]);
+    if (PIN) asm volatile("" : "+v"(s.e[o]), "+v"(s.e[o + 1]));
+  } else if constexpr (K == 7) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.z[i] = s.z[i] * s.e[i];
+    if (PIN) asm volatile("" : "+v"(s.z[0]), "+v"(s.z[1]), "+v"(s.z[2]), "+v"(s.z[3]));
+  } else if constexpr (K == 8) {
+    s.q1[0] = s.q1[1] = 0u;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(s.q1[0]) : "v"(s.z[0]), "v"(tn));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(s.q1[0]) : "v"(s.z[1]), "v"(tn));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(s.q1[1]) : "v"(s.z[2]), "v"(tn));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(s.q1[1]) : "v"(s.z[3]), "v"(tn));
+    if (PIN) asm volatile("" : "+v"(s.q1[0]), "+v"(s.q1[1]));
+  } else if constexpr (K == 9) {
+    s.q2[0] = s.q2[1] = 0u;
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(s.q2[0]) : "v"(s.z[0]), "v"(tn), "v"(s.q1[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(s.q2[0]) : "v"(s.z[1]), "v"(tn), "v"(s.q1[0]));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(s.q2[1]) : "v"(s.z[2]), "v"(tn), "v"(s.q1[1]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(s.q2[1]) : "v"(s.z[3]), "v"(tn), "v"(s.q1[1]));
+    if (PIN) asm volatile("" : "+v"(s.q2[0]), "+v"(s.q2[1]));
+  }
+}
+template <bool PIN>
+__device__ __forceinline__ void epi_all(Epi4 &s, const f32x16 &d, int q, float inv, const f32x4 &bv, float tn) {
+  epi_stage<0, PIN>(s, d, q, inv, bv, tn); epi_stage<1, PIN>(s, d, q, inv, bv, tn); epi_stage<2, PIN>(s, d, q, inv, bv, tn);
+  epi_stage<3, PIN>(s, d, q, inv, bv, tn); epi_stage<4, PIN>(s, d, q, inv, bv, tn); epi_stage<5, PIN>(s, d, q, inv, bv, tn);
+  epi_stage<6, PIN>(s, d, q, inv, bv, tn); epi_stage<7, PIN>(s, d, q, inv, bv, tn); epi_stage<8, PIN>(s, d, q, inv, bv, tn);
+  epi_stage<9, PIN>(s, d, q, inv, bv, tn);
+}
+
 template <int S0, int OTP>   // k-slabs of the input layer (in_pad <= 16 S0); output n-tiles, 2 or 4 (2 out_dim <= 32 OTP)
 __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
   constexpr int XSTR = 16 * S0 + 8;
-  constexpr int U = 2 * OTP;             // output units per 64-row half: (output tile, row tile)
-  constexpr int KS = 8 / U;              // k halves: 2 (OTP == 2) or 1 (OTP == 4)
-  constexpr int SPK = 32 / KS;           // slabs per unit
+  constexpr int NPASS = OTP / 2;         // output tiles are taken two at a time
+  constexpr int NUNIT = RT * NPASS;      // (row tile, pass) units of the tail
   constexpr int O_PAD = 32 * OTP;
   constexpr int W0P = NTC * S0 * 2;      // 1-KB pieces of one W0 chunk
-  constexpr int W2D = 8;                 // output-layer weight fragments in flight (slabs)
   const MlpKernelArgs &p = a.m;
   extern __shared__ f32x4 smem4[];
   char *smem = reinterpret_cast<char *>(smem4);
   _Float16 *cbuf = reinterpret_cast<_Float16 *>(smem);                               // [2][2][128][CSTR]
   _Float16 *ximg = reinterpret_cast<_Float16 *>(smem + 2 * CBUF_BYTES);              // [2][128][XSTR]
   f16x8 *w0buf = reinterpret_cast<f16x8 *>(smem + 2 * CBUF_BYTES + ximg_bytes(S0));   // [2][W0P][64]
-  _Float16 *h2img = reinterpret_cast<_Float16 *>(smem);                              // [2][64][HSTR]
-  float *stg = reinterpret_cast<float *>(smem);                                      // [64][SW]
-  float *part = reinterpret_cast<float *>(smem + OFF_PART);                          // [4][16][64]
+  f32x4 *pbuf = reinterpret_cast<f32x4 *>(smem);                                     // [2][8 waves][2 tiles][4][64] x 16 B
+  float *stg = reinterpret_cast<float *>(smem + 2 * PBUF_BYTES);                     // [2][32][SWS]
   float *cst = reinterpret_cast<float *>(smem + off_const(S0));
   float *bias0 = cst, *bias1 = cst + HIDH, *hc_a = cst + 2 * HIDH, *hc_c = hc_a + 128;
   int *rowidx = reinterpret_cast<int *>(hc_c + 128);
@@ -205,7 +267,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
   float *in_mu_l = r_inv2 + ROWSH, *in_sig_l = in_mu_l + 64;
 
   const int n_rows = p.n_rows_dev ? *p.n_rows_dev : p.n_rows;
-  const int out = p.out_dim, SW = (2 * out) | 1;
+  const int out = p.out_dim;
   if (threadIdx.x < 64) {   // input scaler, once per workgroup (TensorStandardScaler.transform, models/pens/utils.py:156)
     const int k = threadIdx.x;
     in_mu_l[k] = (p.in_mu && k < p.in_dim) ? p.in_mu[k] : 0.0f;
@@ -276,9 +338,10 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
     // ---- stage: constants, per-row scales, the split input image, the first two W0 chunks --------------------------
     const f16x8 *w0e = a.w0 + (size_t)e * a.w0_stride;
     {
-      f16x8 w0r[(2 * W0P + kWavesH - 1) / kWavesH];
+      constexpr int W0R = (2 * W0P + kWavesH - 1) / kWavesH;
+      f16x8 w0r[W0R];
 #pragma unroll
-      for (int u = 0; u < (2 * W0P + kWavesH - 1) / kWavesH; ++u) {
+      for (int u = 0; u < W0R; ++u) {
         const int j = wave + kWavesH * u;
         w0r[u] = w0e[(size_t)(j < 2 * W0P ? j : 0) * 64 + lane];
       }
@@ -329,7 +392,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
         d1[0] = q1[0]; d1[1] = q1[1]; d2[0] = q2[0]; d2[1] = q2[1];
       }
 #pragma unroll
-      for (int u = 0; u < (2 * W0P + kWavesH - 1) / kWavesH; ++u) {
+      for (int u = 0; u < W0R; ++u) {
         const int j = wave + kWavesH * u;
         if (j < 2 * W0P) w0buf[(size_t)j * 64 + lane] = w0r[u];     // chunks 0, 1
       }
@@ -342,35 +405,22 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
     // ---- layers 0 + 1, fused over the 8 chunks of h1 -------------------------------------------------------------------
     const int l0_tn = wave & (NTC - 1), l0_bt = wave / NTC;     // this wave's (n-tile, row-tile) pair of every chunk
     const float inv0_l = r_inv0[32 * l0_bt + r], t1_l = r_t1[32 * l0_bt + r];
-    auto layer0_chunk = [&](int cc) {
-      f32x16 d;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) d[i] = 0.0f;
-      const f16x8 *wa = w0buf + ((size_t)(cc & 1) * W0P + (size_t)l0_tn * S0 * 2) * 64 + lane;
-      const _Float16 *xb0 = ximg + (size_t)(32 * l0_bt + r) * XSTR + 8 * hh;
-#pragma unroll
-      for (int s = 0; s < S0; ++s) {
-        const f16x8 a1 = wa[(size_t)(2 * s) * 64], a2 = wa[(size_t)(2 * s + 1) * 64];
-        const f16x8 b1 = *reinterpret_cast<const f16x8 *>(xb0 + 16 * s);
-        const f16x8 b2 = *reinterpret_cast<const f16x8 *>(xb0 + (size_t)ROWSH * XSTR + 16 * s);
-        mm3(d, a1, a2, b1, b2);
-      }
-      _Float16 *c1 = cbuf + (size_t)(cc & 1) * (CBUF_BYTES / 2) + (size_t)(32 * l0_bt + r) * CSTR + 32 * l0_tn + 4 * hh;
-      _Float16 *c2 = c1 + (size_t)ROWSH * CSTR;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias0 + cc * CK + 32 * l0_tn + 8 * q + 4 * hh);
-        f16x4 o1, o2;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const float z = d[4 * q + s] * inv0_l + bv[s];
-          _Float16 e1, e2;
-          split_h(swishf(z) * t1_l, e1, e2);
-          o1[s] = e1; o2[s] = e2;
-        }
-        *reinterpret_cast<f16x4 *>(c1 + 8 * q) = o1;
-        *reinterpret_cast<f16x4 *>(c2 + 8 * q) = o2;
-      }
+    const _Float16 *xb0 = ximg + (size_t)(32 * l0_bt + r) * XSTR + 8 * hh;
+    // layer-0 operands of one 16-deep slab: W0 fragments of the chunk (LDS copy) and this wave's rows of the x image
+    struct L0Ops { f16x8 a1, a2, b1, b2; };
+    auto l0_read = [&](L0Ops &o, int cc, int s) {
+      const f16x8 *wa = w0buf + ((size_t)(cc & 1) * W0P + (size_t)l0_tn * S0 * 2 + 2 * s) * 64 + lane;
+      o.a1 = wa[0]; o.a2 = wa[64];
+      o.b1 = *reinterpret_cast<const f16x8 *>(xb0 + 16 * s);
+      o.b2 = *reinterpret_cast<const f16x8 *>(xb0 + (size_t)ROWSH * XSTR + 16 * s);
+    };
+    auto l0_store = [&](const Epi4 &s, int cc, int q) {
+      _Float16 *c1 = cbuf + (size_t)(cc & 1) * (CBUF_BYTES / 2) + (size_t)(32 * l0_bt + r) * CSTR + 32 * l0_tn + 4 * hh + 8 * q;
+      *reinterpret_cast<uint2 *>(c1) = make_uint2(s.q1[0], s.q1[1]);
+      *reinterpret_cast<uint2 *>(c1 + (size_t)ROWSH * CSTR) = make_uint2(s.q2[0], s.q2[1]);
+    };
+    auto l0_bias = [&](int cc, int q) {
+      return *reinterpret_cast<const f32x4 *>(bias0 + cc * CK + 32 * l0_tn + 8 * q + 4 * hh);
     };
 
     f32x16 acc[2][RT];
@@ -382,7 +432,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
         for (int i = 0; i < 16; ++i) acc[t][bt][i] = 0.0f;
     const f16x8 *w1a = a.w1 + (size_t)e * a.w1_stride + (size_t)(2 * wave) * 32 * 128 + lane;   // [tile][slab 32][piece][lane]
     f16x8 A[2][2][2];      // [ping-pong][n-tile][piece]
-    f16x8 Bg[2][2][2];     // [row-tile pair][row tile][piece]
+    f16x8 Bt[3][2];        // rolling window over the (slab, row tile) sequence: current, +1, +2 (two LDS reads in flight)
     auto load_a = [&](f16x8 (&x)[2][2], int s) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -390,66 +440,106 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
         x[t][0] = q[0]; x[t][1] = q[64];
       }
     };
-    auto read_b = [&](f16x8 (&x)[2][2], const _Float16 *img, int g, int sl) {
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const _Float16 *q = img + (size_t)(32 * (2 * g + b) + r) * CSTR + 16 * sl + 8 * hh;
-        x[b][0] = *reinterpret_cast<const f16x8 *>(q);
-        x[b][1] = *reinterpret_cast<const f16x8 *>(q + (size_t)ROWSH * CSTR);
-      }
+    auto read_bt = [&](f16x8 (&x)[2], const _Float16 *img, int bt, int sl) {
+      const _Float16 *q = img + (size_t)(32 * bt + r) * CSTR + 16 * sl + 8 * hh;
+      x[0] = *reinterpret_cast<const f16x8 *>(q);
+      x[1] = *reinterpret_cast<const f16x8 *>(q + (size_t)ROWSH * CSTR);
     };
     load_a(A[0], 0);
-    layer0_chunk(0);
+    {   // chunk 0 of h1: nothing to overlap it with yet
+      f32x16 d;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) d[i] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < S0; ++s) {
+        L0Ops o;
+        l0_read(o, 0, s);
+        mm3(d, o.a1, o.a2, o.b1, o.b2);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Epi4 es;
+        const f32x4 bv = l0_bias(0, q);
+        epi_all<false>(es, d, q, inv0_l, bv, t1_l);
+        l0_store(es, 0, q);
+      }
+    }
     __syncthreads();
     H3_STAMP(2);
 
-    // The two waves of a SIMD run the step's halves in opposite order: waves 0-3 produce chunk c + 1 (LDS reads, 9 MFMAs,
-    // swish / split VALU, LDS writes) and then run the layer-1 slabs of chunk c, waves 4-7 run the slabs first -- one
-    // wave's non-matrix work stands beside its partner's MFMAs instead of beside its partner's non-matrix work.
-    const bool late = wave >= kWavesH / 2;
+    // One step = the 96 layer-1 MFMAs of chunk c (8 groups of 12: slab x row-tile pair) with the production of chunk
+    // c + 1 dealt out between them: a wave issues in order, so what stands between two MFMAs runs in the shadow of the
+    // first.  Groups 0 .. S0-1 carry the layer-0 MFMAs of one input slab each (operands read one group ahead), groups
+    // 4 .. 7 one quarter of the swish / lift / split epilogue each, one piece behind every MFMA.  The last step produces a
+    // chunk nobody reads (branch-free; its reads stay inside the workgroup's LDS).
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
-      f16x8 wst[2];
+      f16x8 wst;
       const bool stage_w0 = c + 2 < NCH;
-      if (stage_w0) {   // W0 fragments of chunk c + 2: requested now, written to LDS at the end of the step
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int j = wave + kWavesH * u;
-          wst[u] = w0e[((size_t)(c + 2) * W0P + (j < W0P ? j : 0)) * 64 + lane];
-        }
-      }
-      if (!late && c + 1 < NCH) layer0_chunk(c + 1);
-      H3_STAMP(3);
+      const int cw = stage_w0 ? c + 2 : NCH - 1;
       const _Float16 *img = cbuf + (size_t)(c & 1) * (CBUF_BYTES / 2);
-      read_b(Bg[0], img, 0, 0);
+      f32x16 d;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) d[i] = 0.0f;
+      L0Ops l0;
+      Epi4 es;
+      f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+      read_bt(Bt[0], img, 0, 0);
+      read_bt(Bt[1], img, 1, 0);
+      l0_read(l0, c + 1, 0);
 #pragma unroll
       for (int sl = 0; sl < SLC; ++sl) {
         const int s = c * SLC + sl;
         f16x8(&Ac)[2][2] = A[sl & 1];
         f16x8(&An)[2][2] = A[(sl & 1) ^ 1];
-        load_a(An, s + 1 < 32 ? s + 1 : s);
-        read_b(Bg[1], img, 1, sl);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int g = 0; g < 2; ++g) {
+          const int slot = 2 * sl + g;
+          if (g == 0) load_a(An, s + 1 < 32 ? s + 1 : s);
+          if (slot >= 4) bv = l0_bias(c + 1, slot - 4);
+          // W0 fragments of chunk c + 2 pass through four registers, one 1-KB piece at a time
+          if (slot == 4) wst = w0e[((size_t)cw * W0P + wave) * 64 + lane];
+          if (slot == 5 && W0P > kWavesH) {
+            if (stage_w0) w0buf[((size_t)(c & 1) * W0P + wave) * 64 + lane] = wst;
+            wst = w0e[((size_t)cw * W0P + (wave + kWavesH < W0P ? wave + kWavesH : wave)) * 64 + lane];
+          }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int b = 0; b < 2; ++b) mm3(acc[t][b], Ac[t][0], Ac[t][1], Bg[0][b][0], Bg[0][b][1]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (sl + 1 < SLC) read_b(Bg[0], img, 0, sl + 1);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) mm3(acc[t][2 + b], Ac[t][0], Ac[t][1], Bg[1][b][0], Bg[1][b][1]);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int i = 0; i < 12; ++i) {
+            const int b = i / 6, t = (i / 3) % 2, term = i % 3;
+            const int pos = 4 * sl + 2 * g + b;                     // position in the (slab, row tile) sequence
+            if (i % 6 == 0 && pos + 2 < 4 * SLC) read_bt(Bt[(pos + 2) % 3], img, (pos + 2) & 3, (pos + 2) >> 2);
+            f32x16 &ac = acc[t][2 * g + b];
+            const f16x8 &b1 = Bt[pos % 3][0], &b2 = Bt[pos % 3][1];
+            if (term == 0) ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[t][1], b1, ac, 0, 0, 0);
+            else if (term == 1) ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[t][0], b2, ac, 0, 0, 0);
+            else ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[t][0], b1, ac, 0, 0, 0);
+            if (slot < S0 && i == 5) {          // layer-0 MFMAs of input slab `slot`, then the next slab's operands
+              mm3(d, l0.a1, l0.a2, l0.b1, l0.b2);
+              if (slot + 1 < S0) l0_read(l0, c + 1, slot + 1);
+            }
+            if (slot >= 4) {
+              const int q = slot - 4;
+              if (i == 0) epi_stage<0, true>(es, d, q, inv0_l, bv, t1_l);
+              if (i == 1) epi_stage<1, true>(es, d, q, inv0_l, bv, t1_l);
+              if (i == 2) epi_stage<2, true>(es, d, q, inv0_l, bv, t1_l);
+              if (i == 3) epi_stage<3, true>(es, d, q, inv0_l, bv, t1_l);
+              if (i == 4) epi_stage<4, true>(es, d, q, inv0_l, bv, t1_l);
+              if (i == 5) epi_stage<5, true>(es, d, q, inv0_l, bv, t1_l);
+              if (i == 6) epi_stage<6, true>(es, d, q, inv0_l, bv, t1_l);
+              if (i == 7) epi_stage<7, true>(es, d, q, inv0_l, bv, t1_l);
+              if (i == 8) epi_stage<8, true>(es, d, q, inv0_l, bv, t1_l);
+              if (i == 9) epi_stage<9, true>(es, d, q, inv0_l, bv, t1_l);
+              if (i == 10) l0_store(es, c + 1, q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       }
       H3_STAMP(4);
-      if (late && c + 1 < NCH) layer0_chunk(c + 1);
       if (stage_w0) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int j = wave + kWavesH * u;
-          if (j < W0P) w0buf[((size_t)(c & 1) * W0P + j) * 64 + lane] = wst[u];
-        }
+        const int j = W0P > kWavesH ? wave + kWavesH : wave;
+        if (j < W0P) w0buf[((size_t)(c & 1) * W0P + j) * 64 + lane] = wst;
       }
       __syncthreads();
       H3_STAMP(5);
@@ -460,98 +550,115 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
     fetch_bias(item + gridDim.x, tid);
     H3_STAMP(6);
 
-    // ---- tail: h2 -> output layer -> head -> stores, one 64-row half at a time ---------------------------------------
-    const int u_id = wave % U, ks = wave / U;                      // (KS == 1: ks == 0 for every wave)
-    const int t2i = u_id >> 1, btl = u_id & 1;
-    const f16x8 *wq = a.w2 + (size_t)e * a.w2_stride + lane + ((size_t)t2i * 32 + (size_t)ks * SPK) * 128;   // [tile][slab][piece][lane]
+    // ---- tail: h2 -> output layer -> head -> stores, one (32-row tile, pair of output tiles) unit at a time.
+    // h2 never leaves the registers: an accumulator tile's rows are the next product's k index, so the wave's own 64 hidden
+    // units (4 slabs) are its slice of the output layer's K (W2 images packed in the matching k order), and the eight
+    // waves' partial outputs are added up through LDS in a fixed order.
+    const f16x8 *w2w = a.w2 + (size_t)e * a.w2_stride + lane + (size_t)(4 * wave) * 128;   // + (tile * 32 + S) * 128 + piece * 64
+    auto reduce_unit = [&](int u) {
+      // wave w adds up registers 4q .. 4q+3 (q = w & 3) of output tile tt = w >> 2 of this unit over the eight waves,
+      // applies the head (models/pens/pe.py:815-835) and leaves the values in the staging tile [row][column of the pair]
+      const int rt = u / NPASS, pass = u % NPASS;
+      const int tt = wave >> 2, q = wave & 3;
+      const f32x4 *pp = pbuf + ((size_t)(u & 1) * 64 + (size_t)tt * 4 + q) * 64 + lane;
+      f32x4 v = pp[0];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      // the first output-layer weight fragments: requested ahead of the epilogue that hides their latency
-      f16x8 wa[W2D][2];
+      for (int wv = 1; wv < kWavesH; ++wv) v += pp[(size_t)wv * 8 * 64];
+      const int nl = 32 * tt + 8 * q + 4 * hh, n = 64 * pass + nl;
+      const f32x4 ha = *reinterpret_cast<const f32x4 *>(hc_a + n), hc = *reinterpret_cast<const f32x4 *>(hc_c + n);
+      const float inv2_l = r_inv2[32 * rt + r];
+      float *sg = stg + (size_t)(u & 1) * 32 * SWS + r * SWS + nl;
 #pragma unroll
-      for (int d = 0; d < W2D; ++d) { wa[d][0] = wq[(size_t)d * 128]; wa[d][1] = wq[(size_t)d * 128 + 64]; }
-      // (a) this half of h2: swish, lift, split, image
+      for (int s = 0; s < 4; ++s) {
+        float y = ha[s] * (v[s] * inv2_l) + hc[s];
+        if (n + s >= out) y = __expf(y);
+        sg[s] = y;
+      }
+    };
+    auto store_unit = [&](int u) {
+      // a row's means / variances are contiguous runs of `out` floats; lane = column of the pair
+      const int rt = u / NPASS, pass = u % NPASS;
+      const int n = 64 * pass + lane;
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int rowi = 32 * (2 * hf + b) + r;
-        const float inv1_l = r_inv1[rowi], t2_l = r_t2[rowi];
-        _Float16 *c1 = h2img + (size_t)(32 * b + r) * HSTR + 64 * wave + 4 * hh;
-        _Float16 *c2 = c1 + (size_t)64 * HSTR;
+      for (int j = 0; j < 4; ++j) {
+        const int rl = wave + kWavesH * j;
+        const int rr = rowidx[32 * rt + rl];
+        const float y = stg[(size_t)(u & 1) * 32 * SWS + rl * SWS + lane];
+        if (rr >= 0 && n < 2 * out) {
+          const size_t obase = ((size_t)e * p.ld_rows + rr) * out;
+          if (n < out) p.out0[obase + n] = y;
+          else p.out1[obase + (n - out)] = y;
+        }
+      }
+    };
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+    for (int rt = 0; rt < RT; ++rt) {
+      f16x8 wf[2][2][2];       // [ping-pong][output tile of the pair][piece]
+      auto load_w2 = [&](f16x8 (&x)[2][2], int pass, int S) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const f16x8 *q = w2w + ((size_t)(2 * pass + tt) * 32 + S) * 128;
+          x[tt][0] = q[0]; x[tt][1] = q[64];
+        }
+      };
+      load_w2(wf[0], 0, 0);
+      // this row tile of h2: swish, lift, split -- straight into B fragments
+      f16x8 bf[4][2];
+      {
+        u32x4 bfu[4][2];
+        const float inv1_l = r_inv1[32 * rt + r], t2_l = r_t2[32 * rt + r];
+#pragma unroll
+        for (int S = 0; S < 4; ++S)
+#pragma unroll
+          for (int jq = 0; jq < 2; ++jq) {
+            const int q = 2 * (S & 1) + jq;
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias1 + 64 * wave + 32 * (S >> 1) + 8 * q + 4 * hh);
+            Epi4 es;
+            epi_all<false>(es, acc[S >> 1][rt], q, inv1_l, bv, t2_l);
+            bfu[S][0][2 * jq] = es.q1[0]; bfu[S][0][2 * jq + 1] = es.q1[1];
+            bfu[S][1][2 * jq] = es.q2[0]; bfu[S][1][2 * jq + 1] = es.q2[1];
+          }
+#pragma unroll
+        for (int S = 0; S < 4; ++S)
+#pragma unroll
+          for (int pc = 0; pc < 2; ++pc) bf[S][pc] = __builtin_bit_cast(f16x8, bfu[S][pc]);
+      }
+#pragma unroll
+      for (int pass = 0; pass < NPASS; ++pass) {
+        const int u = rt * NPASS + pass;
+        f32x16 o[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[tt][i] = 0.0f;
+#pragma unroll
+        for (int S = 0; S < 4; ++S) {
+          const int nS = (S + 1) & 3, npass = (S == 3) ? pass + 1 : pass;
+          if (S < 3 || pass + 1 < NPASS) load_w2(wf[(S & 1) ^ 1], npass, nS);
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) mm3(o[tt], wf[S & 1][tt][0], wf[S & 1][tt][1], bf[S][0], bf[S][1]);
+        }
+        f32x4 *pw = pbuf + ((size_t)(u & 1) * 64 + (size_t)wave * 8) * 64 + lane;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias1 + 64 * wave + 32 * t + 8 * q + 4 * hh);
-            f16x4 o1, o2;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              const float z = acc[t][2 * hf + b][4 * q + s] * inv1_l + bv[s];
-              _Float16 e1, e2;
-              split_h(swishf(z) * t2_l, e1, e2);
-              o1[s] = e1; o2[s] = e2;
-            }
-            *reinterpret_cast<f16x4 *>(c1 + 32 * t + 8 * q) = o1;
-            *reinterpret_cast<f16x4 *>(c2 + 32 * t + 8 * q) = o2;
+            const f32x4 v = {o[tt][4 * q], o[tt][4 * q + 1], o[tt][4 * q + 2], o[tt][4 * q + 3]};
+            pw[(size_t)(tt * 4 + q) * 64] = v;
           }
+        H3_STAMP(7);
+        __syncthreads();       // unit u's partials are complete; unit u - 1's staging tile too
+        H3_STAMP(8);
+        if (u > 0) store_unit(u - 1);
+        reduce_unit(u);
+        H3_STAMP(9);
       }
-      H3_STAMP(7);
-      __syncthreads();
-      // (b) output layer: unit (t2i, btl), slabs [ks SPK, (ks + 1) SPK)
-      f32x16 o;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) o[i] = 0.0f;
-      {
-        const _Float16 *hq = h2img + (size_t)(32 * btl + r) * HSTR + 16 * ks * SPK + 8 * hh;
-#pragma unroll
-        for (int s = 0; s < SPK; ++s) {
-          const f16x8 b1 = *reinterpret_cast<const f16x8 *>(hq + 16 * s);
-          const f16x8 b2 = *reinterpret_cast<const f16x8 *>(hq + (size_t)64 * HSTR + 16 * s);
-          mm3(o, wa[s % W2D][0], wa[s % W2D][1], b1, b2);
-          if (s + W2D < SPK) {
-            wa[s % W2D][0] = wq[(size_t)(s + W2D) * 128];
-            wa[s % W2D][1] = wq[(size_t)(s + W2D) * 128 + 64];
-          }
-        }
-      }
-      if (KS == 2 && ks == 1) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) part[(u_id * 16 + i) * 64 + lane] = o[i];
-      }
-      H3_STAMP(8);
-      __syncthreads();     // every read of the h2 image is done: the region becomes the output staging tile
-      // (c) head (models/pens/pe.py:815-835): mean = sig (o + b2) + mu ; var = exp(2 log sig + o' + b2')
-      if (ks == 0) {
-        const float inv2_l = r_inv2[32 * (2 * hf + btl) + r];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int n = 32 * t2i + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          float v = o[i];
-          if (KS == 2) v += part[(u_id * 16 + i) * 64 + lane];
-          float y = hc_a[n] * (v * inv2_l) + hc_c[n];
-          if (n >= out) y = __expf(y);
-          if (n < 2 * out) stg[(32 * btl + r) * SW + n] = y;
-        }
-      }
-      H3_STAMP(9);
-      __syncthreads();
-      // (d) stores: a row's means / variances are contiguous runs of `out` floats
-#pragma unroll 1
-      for (int j = 0; j < 8; ++j) {
-        const int rl = wave + kWavesH * j;                 // row of this half
-        const int rr = rowidx[64 * hf + rl];
-        if (rr >= 0) {
-          const size_t obase = ((size_t)e * p.ld_rows + rr) * out;
-          for (int n = lane; n < 2 * out; n += 64) {
-            const float y = stg[rl * SW + n];
-            if (n < out) p.out0[obase + n] = y;
-            else p.out1[obase + (n - out)] = y;
-          }
-        }
-      }
-      H3_STAMP(10);
-      __syncthreads();     // the staging tile is overwritten by the next half's image / the next item's stage
-      H3_STAMP(11);
     }
+    __syncthreads();
+    store_unit(NUNIT - 1);
+    H3_STAMP(10);
+    __syncthreads();     // the LDS regions are rewritten by the next item's stage
+    H3_STAMP(11);
   }  // persistent item loop
 #ifdef CMBPO_STAMPS
   if (p.stamps && threadIdx.x == 0) {
@@ -599,7 +706,7 @@ static int ensure_h3(cmbpo_mlp *m, hipStream_t s) {
     const long total = (long)tiles[l] * slabs[l] * 64 * E;
     hipLaunchKernelGGL(h3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, m->d_blob + src_off[l], src_stride,
                        kg[l], src_tiles[l], reinterpret_cast<f16x8 *>(m->d_h3) + m->h3_off[l], m->h3_stride[l], tiles[l], slabs[l],
-                       E, stats, l);
+                       E, stats, l, l == 2 ? 1 : 0);
   }
   CMBPO_HIP_CHECK(hipGetLastError());
   m->h3_version = m->pack_version;
@@ -637,7 +744,6 @@ int cmbpo_internal_launch_h3(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
   const int S0 = m->h3_s0, OTP = m->h3_otp;
   const size_t lds = (size_t)lds_bytes(S0);
   CMBPO_REQUIRE(lds <= 160 * 1024, "ens_h3: LDS budget exceeded (%zu B)", lds);
-  CMBPO_REQUIRE((size_t)64 * ((2 * m->out_dim) | 1) * 4 <= (size_t)OFF_PART, "ens_h3: staging tile does not fit");
   const int grid = k.m.n_items < n_cu ? k.m.n_items : n_cu;
   static size_t attr_done[5][5] = {};
 #define CMBPO_H3_CASE(S0_, OTP_)                                                                                       \

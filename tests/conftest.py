@@ -26,5 +26,7 @@ def ens_path(hip_lib, request):
     from cmbpo_amd import _lib
     before = hip_lib.cmbpo_get_ens_matrix_path()
     _lib.check(hip_lib.cmbpo_set_ens_matrix_path(request.param), "cmbpo_set_ens_matrix_path")
+    hip_lib.cmbpo_set_ens_f16_min_rows(0)          # the f16 path at every size, also below its default threshold
     yield request.param
     hip_lib.cmbpo_set_ens_matrix_path(before)
+    hip_lib.cmbpo_set_ens_f16_min_rows(1536)

@@ -248,6 +248,7 @@ def test_ens_matrix_paths_agree_and_follow_weight_updates(hip_lib):
     x = rng.standard_normal((1000, obs_dim + act_dim)).astype(np.float32)
     out = {}
     before = hip_lib.cmbpo_get_ens_matrix_path()
+    hip_lib.cmbpo_set_ens_f16_min_rows(0)
     try:
         for path in (0, 1, 2):
             assert hip_lib.cmbpo_set_ens_matrix_path(path) == 0
@@ -268,3 +269,4 @@ def test_ens_matrix_paths_agree_and_follow_weight_updates(hip_lib):
         assert hip_lib.cmbpo_set_ens_matrix_path(7) < 0
     finally:
         hip_lib.cmbpo_set_ens_matrix_path(before)
+        hip_lib.cmbpo_set_ens_f16_min_rows(1536)

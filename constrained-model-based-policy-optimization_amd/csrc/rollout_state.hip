@@ -11,6 +11,7 @@
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -431,24 +432,45 @@ __global__ __launch_bounds__(kScanThreads) void compact_scatter_kernel(const cmb
 }
 
 // ---- get(): offsets, moments, flatten ------------------------------------------------------------
-__global__ __launch_bounds__(kScanThreads) void offsets_kernel(const cmbpo_rollout_t r, int32_t *offs) {
+// offsets = exclusive scan of the path lengths, as three short multi-workgroup kernels like the compaction (one
+// workgroup walking 100 k lengths took 110 us): per-chunk sums, a one-workgroup scan of the sums, per-chunk scans.
+// Integer scratch: r.store_part (idle between the rollout and the next reset).
+__global__ __launch_bounds__(kScanThreads) void offsets_count_kernel(const cmbpo_rollout_t r) {
   __shared__ int sm_i[17];
-  const int tid = threadIdx.x;
+  const int b = blockIdx.x * kScanThreads + threadIdx.x;
+  int total;
+  (void)block_excl_scan(b < r.B ? r.len[b] : 0, sm_i, &total);
+  if (threadIdx.x == 0) reinterpret_cast<int *>(r.store_part)[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kScanThreads) void offsets_scan_kernel(const cmbpo_rollout_t r, int n_chunks, int32_t *offs) {
+  __shared__ int sm_i[17];
+  int *cnt = reinterpret_cast<int *>(r.store_part);
   int carry = 0;
-  for (int base = 0; base < r.B; base += kScanThreads) {
-    const int b = base + tid;
-    const int v = (b < r.B) ? r.len[b] : 0;
+  for (int base = 0; base < n_chunks; base += kScanThreads) {
+    const int c = base + threadIdx.x;
+    const int v = (c < n_chunks) ? cnt[c] : 0;
     int total;
     const int excl = block_excl_scan(v, sm_i, &total);
-    if (b < r.B) offs[b] = carry + excl;
+    if (c < n_chunks) cnt[c] = carry + excl;
     carry += total;
   }
-  if (tid == 0) offs[r.B] = carry;
+  if (threadIdx.x == 0) offs[r.B] = carry;
+}
+
+__global__ __launch_bounds__(kScanThreads) void offsets_write_kernel(const cmbpo_rollout_t r, int32_t *offs) {
+  __shared__ int sm_i[17];
+  const int b = blockIdx.x * kScanThreads + threadIdx.x;
+  int total;
+  const int excl = block_excl_scan(b < r.B ? r.len[b] : 0, sm_i, &total);
+  if (b < r.B) offs[b] = reinterpret_cast<const int *>(r.store_part)[blockIdx.x] + excl;
 }
 
 // stats layout: [0] n  [1] adv_mean  [2] adv_std  [3] cadv_mean  [4] ret_mean  [5] cret_mean
 //               [8] n (raw)  [9] sum adv  [10] sum cadv  [11] sum ret  [12] sum cret  [13] sum (adv-mean)^2
-__global__ __launch_bounds__(256) void moments_kernel(const cmbpo_rollout_t r, int pass, double *st) {
+// Every workgroup leaves its float64 partial sums in r.store_part[block][8]; moments_fold_kernel adds them in block
+// order -- no atomics, the statistics (and with them the normalised advantages) are bitwise reproducible.
+__global__ __launch_bounds__(256) void moments_kernel(const cmbpo_rollout_t r, int pass, const double *st) {
   __shared__ double sm_d[16];
   const size_t B = (size_t)r.B;
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
@@ -465,16 +487,26 @@ __global__ __launch_bounds__(256) void moments_kernel(const cmbpo_rollout_t r, i
       }
     }
   }
+  double *part = r.store_part + (size_t)blockIdx.x * 8;
+  const double a0 = block_sum(s0, sm_d);
   if (pass == 0) {
-    const double a0 = block_sum(s0, sm_d), a1 = block_sum(s1, sm_d), a2 = block_sum(s2, sm_d);
+    const double a1 = block_sum(s1, sm_d), a2 = block_sum(s2, sm_d);
     const double a3 = block_sum(s3, sm_d), a4 = block_sum(s4, sm_d);
-    if (threadIdx.x == 0) {
-      atomicAdd(&st[8], a0); atomicAdd(&st[9], a1); atomicAdd(&st[10], a2);
-      atomicAdd(&st[11], a3); atomicAdd(&st[12], a4);
-    }
-  } else {
-    const double a0 = block_sum(s0, sm_d);
-    if (threadIdx.x == 0) atomicAdd(&st[13], a0);
+    if (threadIdx.x == 0) { part[0] = a0; part[1] = a1; part[2] = a2; part[3] = a3; part[4] = a4; }
+  } else if (threadIdx.x == 0) {
+    part[0] = a0;
+  }
+}
+
+__global__ __launch_bounds__(64) void moments_fold_kernel(const cmbpo_rollout_t r, int pass, int n_parts, double *st) {
+  // lane l adds parts l, l + 64, ... in that order, then the 64 lane sums are added in a fixed tree: same result every run
+  const int lane = threadIdx.x;
+  const int nk = pass == 0 ? 5 : 1;
+  for (int k = 0; k < nk; ++k) {
+    double acc = 0.0;
+    for (int i = lane; i < n_parts; i += 64) acc += r.store_part[(size_t)i * 8 + k];
+    acc = wave_sum(acc);
+    if (lane == 0) st[pass == 0 ? 8 + k : 13] = acc;
   }
 }
 
@@ -492,56 +524,191 @@ __global__ void moments_finalize(int pass, double *st) {
   }
 }
 
+// flatten: time-major [t][b][.] buffers -> the reference's branch-major / time-minor list (modelbuffer.py:212-218).
+// Both sides of the copy want long contiguous runs: in the buffers the rows of consecutive BRANCHES at one step are
+// adjacent, in the output the rows of consecutive STEPS of one branch are.  So a workgroup takes a tile of branches, reads
+// step by step (runs of tile x dim floats, one float per lane, consecutive lanes on consecutive addresses), transposes
+// through LDS ([branch][step][dim]) and writes each branch's samples as one run -- the runs of a tile are adjacent, the
+// tile's output is a single contiguous block.  (Reading the output order straight from the buffers touched a 116-byte run
+// per sample: 2.9 TB/s.)  Vector fields: 16-branch tiles (63 KB of LDS for obs at T = 34); scalar fields: 64-branch tiles.
+constexpr int kVecTile = 16;
 constexpr int kFlatRows = 64;
 
 struct FlatArgs {
   float *out[12];
 };
 
-__global__ __launch_bounds__(256) void flatten_kernel(const cmbpo_rollout_t r, const int32_t *offs,
-                                                      const double *st, const FlatArgs fa) {
-  extern __shared__ unsigned short tb[];  // [<= kFlatRows * T]  (b_local << 8) | t
-  const int b0 = blockIdx.x * kFlatRows;
-  const int b1 = min(r.B, b0 + kFlatRows);
-  const int o0 = offs[b0], cnt = offs[b1] - o0;
-  if (cnt == 0) return;
-  for (int e = threadIdx.x; e < (b1 - b0) * r.T; e += blockDim.x) {
-    const int bl = e / r.T, t = e - bl * r.T;
-    const int b = b0 + bl;
-    if (t < r.len[b]) tb[offs[b] - o0 + t] = (unsigned short)((bl << 8) | t);
-  }
-  __syncthreads();
-  const size_t B = (size_t)r.B;
-  const int D = r.obs_dim, A = r.act_dim;
-  const float adv_mean = (float)st[1], adv_den = (float)st[2] + 1e-8f, cadv_mean = (float)st[3];
-  // vector fields: obs (0), act (1), log_std (10), mu (11)
-  const float *vsrc[4] = {r.obs_buf, r.act_buf, r.ls_buf, r.mu_buf};
-  const int vdst[4] = {0, 1, 10, 11};
-  const int vdim[4] = {D, A, A, A};
+// one vector field of the tile: buffer -> LDS ([branch][step][dim]).  Steps go round-robin over the four waves, NU steps
+// per wave and pass, and every load of a pass is requested before the first LDS write: a workgroup pays the HBM latency
+// once per pass, not once per step (at T = 34 one pass covers the tile).
+template <int NU>
+__device__ __forceinline__ void flat_vec_in(float *tile, const float *src, int dim, int nb, int T, int lmax, size_t B, int lane,
+                                            int wave, int tid) {
+  constexpr int KV = 2;                     // 16-byte loads per lane and step: runs of up to 512 floats
+  const int run = nb * dim;                 // floats of the tile at one step: contiguous in the buffer
+  const int c = (T - 1) * dim;
+  // step t, element j = bl * dim + d  ->  tile[(bl * T + t) * dim + d] = tile[j + bl * c + t * dim]
+  if ((run & 3) == 0 && run <= 256 * KV && ((B * dim) & 3) == 0) {
+    int j0[KV], d0[KV], i0[KV];
 #pragma unroll
-  for (int f = 0; f < 4; ++f) {
-    const int dim = vdim[f];
-    float *dst = fa.out[vdst[f]] + (size_t)o0 * dim;
-    for (int e = threadIdx.x; e < cnt * dim; e += blockDim.x) {
-      const int p = e / dim, d = e - p * dim;
-      const int code = tb[p];
-      const size_t src = ((size_t)(code & 255) * B + (b0 + (code >> 8))) * dim + d;
-      dst[e] = vsrc[f][src];
+    for (int k = 0; k < KV; ++k) {
+      j0[k] = 4 * (lane + 64 * k);
+      const int jj = j0[k] < run ? j0[k] : 0;
+      const int bl = jj / dim;
+      d0[k] = jj - bl * dim;
+      i0[k] = jj + bl * c;
+    }
+    const bool two = run > 256;
+    for (int tb = wave; tb < lmax; tb += 4 * NU) {
+      f32x4 v[NU][KV];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int t = min(tb + 4 * u, T - 1);
+        const float *st = src + (size_t)t * B * dim;
+        v[u][0] = *reinterpret_cast<const f32x4 *>(st + (j0[0] < run ? j0[0] : 0));
+        if (two) v[u][1] = *reinterpret_cast<const f32x4 *>(st + (j0[1] < run ? j0[1] : 0));
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int k = 0; k < KV; ++k)
+          if (tb + 4 * u < lmax && j0[k] < run && (k == 0 || two)) {
+            float *q = tile + i0[k] + (tb + 4 * u) * dim;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i + (d0[k] + i >= dim ? c : 0)] = v[u][k][i];
+          }
+    }
+  } else {
+    for (int e = tid; e < lmax * run; e += 256) {
+      const int t = e / run, j = e - t * run;
+      tile[j + ((j / dim) * (T - 1) + t) * dim] = src[(size_t)t * B * dim + j];
     }
   }
-  // scalar fields: adv 2, cadv 3, ret 4, cret 5, logp 6, val 7, cval 8, cost 9
-  for (int p = threadIdx.x; p < cnt; p += blockDim.x) {
-    const int code = tb[p];
-    const size_t src = (size_t)(code & 255) * B + (b0 + (code >> 8));
-    const size_t o = (size_t)o0 + p;
-    fa.out[2][o] = __fsub_rn(r.adv_buf[src], adv_mean) / adv_den;   // modelbuffer.py:199
-    fa.out[3][o] = __fsub_rn(r.cadv_buf[src], cadv_mean);           // modelbuffer.py:204
-    fa.out[4][o] = r.ret_buf[src];
-    fa.out[5][o] = r.cret_buf[src];
-    fa.out[6][o] = r.logp_buf[src];
-    fa.out[7][o] = r.val_buf[src];
-    fa.out[8][o] = r.cval_buf[src];
-    fa.out[9][o] = r.cost_buf[src];
+}
+
+// LDS -> output: branch bl's samples are tile[bl * T * dim ...] for len * dim floats, at dst + (offs - o0) * dim
+__device__ __forceinline__ void flat_vec_out(const float *tile, float *dst, int dim, int nb, int T, int cnt, int o0, const int *lens,
+                                             const int *loffs, int lane, int wave, int tid) {
+  if (cnt == nb * T) {                      // every path full: the tile is already the output block
+    const int n = cnt * dim;
+    if ((((size_t)o0 * dim) & 3) == 0 && (n & 3) == 0) {
+      for (int e = 4 * tid; e < n; e += 1024) *reinterpret_cast<f32x4 *>(dst + e) = *reinterpret_cast<const f32x4 *>(tile + e);
+    } else {
+      for (int e = tid; e < n; e += 256) dst[e] = tile[e];
+    }
+  } else {
+    for (int bl = wave; bl < nb; bl += 4) {
+      const float *tl = tile + (size_t)bl * T * dim;
+      float *d = dst + (size_t)(loffs[bl] - o0) * dim;
+      const int n = lens[bl] * dim;
+      for (int e = lane; e < n; e += 64) d[e] = tl[e];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void flatten_vec_kernel(const cmbpo_rollout_t r, const int32_t *offs, const FlatArgs fa,
+                                                          int vt) {
+  extern __shared__ float tile[];          // [vt][T][obs_dim], then [3][vt][T][act_dim]; vt <= kVecTile branches
+  __shared__ int lens[kVecTile], loffs[kVecTile + 1];
+  const int b0 = blockIdx.x * vt;
+  const int nb = min(r.B - b0, vt);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < kVecTile) lens[tid] = tid < nb ? r.len[b0 + tid] : 0;
+  if (tid <= kVecTile) loffs[tid] = offs[min(b0 + tid, r.B)];
+  __syncthreads();
+  const int o0 = loffs[0], cnt = loffs[nb] - o0;
+  if (cnt == 0) return;
+  int lmax = 0;
+  for (int i = 0; i < nb; ++i) lmax = max(lmax, lens[i]);
+  const size_t B = (size_t)r.B;
+  const int T = r.T, D = r.obs_dim, A = r.act_dim;
+  constexpr int NU = 9;                       // 4 waves x 9 steps: T <= 36 in one pass
+  // obs (output 0)
+  flat_vec_in<NU>(tile, r.obs_buf + (size_t)b0 * D, D, nb, T, lmax, B, lane, wave, tid);
+  __syncthreads();
+  flat_vec_out(tile, fa.out[0] + (size_t)o0 * D, D, nb, T, cnt, o0, lens, loffs, lane, wave, tid);
+  __syncthreads();
+  // act (1), log_std (10), mu (11): three tiles side by side
+  const size_t ts = (size_t)vt * T * A;
+  flat_vec_in<NU>(tile, r.act_buf + (size_t)b0 * A, A, nb, T, lmax, B, lane, wave, tid);
+  flat_vec_in<NU>(tile + ts, r.ls_buf + (size_t)b0 * A, A, nb, T, lmax, B, lane, wave, tid);
+  flat_vec_in<NU>(tile + 2 * ts, r.mu_buf + (size_t)b0 * A, A, nb, T, lmax, B, lane, wave, tid);
+  __syncthreads();
+  flat_vec_out(tile, fa.out[1] + (size_t)o0 * A, A, nb, T, cnt, o0, lens, loffs, lane, wave, tid);
+  flat_vec_out(tile + ts, fa.out[10] + (size_t)o0 * A, A, nb, T, cnt, o0, lens, loffs, lane, wave, tid);
+  flat_vec_out(tile + 2 * ts, fa.out[11] + (size_t)o0 * A, A, nb, T, cnt, o0, lens, loffs, lane, wave, tid);
+}
+
+__global__ __launch_bounds__(256) void flatten_scalar_kernel(const cmbpo_rollout_t r, const int32_t *offs, const double *st,
+                                                             const FlatArgs fa) {
+  extern __shared__ float tile[];          // [8][kFlatRows][T + 1] | position map [kFlatRows * T] (ushort)
+  __shared__ int loffs[kFlatRows + 1];
+  const int b0 = blockIdx.x * kFlatRows;
+  const int nb = min(r.B - b0, kFlatRows);
+  const int tid = threadIdx.x;
+  if (tid <= kFlatRows) loffs[tid] = offs[min(b0 + tid, r.B)];
+  __syncthreads();
+  const int o0 = loffs[0], cnt = loffs[nb] - o0;
+  if (cnt == 0) return;
+  const size_t B = (size_t)r.B;
+  const int T = r.T, TS = T + 1;
+  const size_t fs = (size_t)kFlatRows * TS;          // floats of one field's tile
+  unsigned short *map = reinterpret_cast<unsigned short *>(tile + 8 * fs);   // output position -> bl * TS + t
+  int lmax = 0;
+  for (int e = tid; e < nb * T; e += 256) {
+    const int bl = e / T, t = e - bl * T;
+    if (t < loffs[bl + 1] - loffs[bl]) map[loffs[bl] - o0 + t] = (unsigned short)(bl * TS + t);
+  }
+  for (int i = 0; i < nb; ++i) lmax = max(lmax, loffs[i + 1] - loffs[i]);
+  const float adv_mean = (float)st[1], adv_den = (float)st[2] + 1e-8f, cadv_mean = (float)st[3];
+  // adv 2, cadv 3, ret 4, cret 5, logp 6, val 7, cval 8, cost 9: all eight fields in one pass
+  const float *ssrc[8] = {r.adv_buf, r.cadv_buf, r.ret_buf, r.cret_buf, r.logp_buf, r.val_buf, r.cval_buf, r.cost_buf};
+  if (nb == kFlatRows && (B & 3) == 0) {
+    // 16 lanes x 16 bytes = the tile's 64 branches of one step; steps ts, ts + 16, ...; every load of a pass of 48 steps
+    // is requested before the first LDS write
+    const int l16 = tid & 15, ts = tid >> 4;
+    constexpr int NUS = 3;
+    for (int tb = ts; tb < lmax; tb += 16 * NUS) {
+      f32x4 v[8][NUS];
+#pragma unroll
+      for (int g = 0; g < 8; ++g)
+#pragma unroll
+        for (int u = 0; u < NUS; ++u) {
+          const int t = min(tb + 16 * u, T - 1);
+          v[g][u] = *reinterpret_cast<const f32x4 *>(ssrc[g] + (size_t)t * B + b0 + 4 * l16);
+        }
+#pragma unroll
+      for (int g = 0; g < 8; ++g)
+#pragma unroll
+        for (int u = 0; u < NUS; ++u)
+          if (tb + 16 * u < lmax) {
+            float *tl = tile + g * fs + (4 * l16) * TS + tb + 16 * u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tl[i * TS] = v[g][u][i];
+          }
+    }
+  } else {
+    const int bl_in = tid & 63, tq = tid >> 6;        // lanes over branches, waves over steps
+    for (int g = 0; g < 8; ++g) {
+      const float *src = ssrc[g] + b0 + min(bl_in, nb - 1);
+      float *tl = tile + g * fs + bl_in * TS;
+      for (int t = tq; t < lmax; t += 4) {
+        const float x = src[(size_t)t * B];
+        if (bl_in < nb) tl[t] = x;
+      }
+    }
+  }
+  __syncthreads();
+  for (int pq = tid; pq < cnt; pq += 256) {
+    const int code = map[pq];
+    const size_t o = (size_t)o0 + pq;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      float v = tile[g * fs + code];
+      if (g == 0) v = __fsub_rn(v, adv_mean) / adv_den;     // modelbuffer.py:199
+      if (g == 1) v = __fsub_rn(v, cadv_mean);              // modelbuffer.py:204
+      fa.out[2 + g][o] = v;
+    }
   }
 }
 
@@ -630,7 +797,11 @@ extern "C" int cmbpo_rollout_compact(const cmbpo_rollout_t *r, void *stream) {
 extern "C" int cmbpo_buffer_offsets(const cmbpo_rollout_t *r, int32_t *d_offsets, void *stream) {
   if (int rc = check_rollout(r, "cmbpo_buffer_offsets")) return rc;
   CMBPO_REQUIRE(d_offsets != nullptr, "cmbpo_buffer_offsets: NULL offsets");
-  hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r, d_offsets);
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = cmbpo_ceil_div(r->B, kScanThreads);     // <= ceil(B / 64) * 2 ints of r->store_part
+  hipLaunchKernelGGL(offsets_count_kernel, dim3(chunks), dim3(kScanThreads), 0, s, *r);
+  hipLaunchKernelGGL(offsets_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, *r, chunks, d_offsets);
+  hipLaunchKernelGGL(offsets_write_kernel, dim3(chunks), dim3(kScanThreads), 0, s, *r, d_offsets);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }
@@ -641,8 +812,12 @@ extern "C" int cmbpo_buffer_moments(const cmbpo_rollout_t *r, int pass, double *
   hipStream_t s = (hipStream_t)stream;
   if (pass == 0) CMBPO_HIP_CHECK(hipMemsetAsync(d_stats, 0, 16 * sizeof(double), s));
   if (pass == 0 || pass == 2) {
-    const int blocks = cmbpo_ceil_div(r->B, 256) < 1024 ? cmbpo_ceil_div(r->B, 256) : 1024;
+    // one partial row of r->store_part per workgroup: at most ceil(B / 64) rows exist
+    const int cap = cmbpo_ceil_div(r->B, 64);
+    int blocks = cmbpo_ceil_div(r->B, 256) < 1024 ? cmbpo_ceil_div(r->B, 256) : 1024;
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(moments_kernel, dim3(blocks), dim3(256), 0, s, *r, pass == 0 ? 0 : 1, d_stats);
+    hipLaunchKernelGGL(moments_fold_kernel, dim3(1), dim3(64), 0, s, *r, pass == 0 ? 0 : 1, blocks, d_stats);
   } else {
     hipLaunchKernelGGL(moments_finalize, dim3(1), dim3(1), 0, s, pass, d_stats);
   }
@@ -659,9 +834,30 @@ extern "C" int cmbpo_buffer_flatten(const cmbpo_rollout_t *r, const int32_t *d_o
     CMBPO_REQUIRE(h_out12[k] != nullptr, "cmbpo_buffer_flatten: output %d is NULL", k);
     fa.out[k] = h_out12[k];
   }
-  const size_t lds = (size_t)kFlatRows * r->T * sizeof(unsigned short);
-  hipLaunchKernelGGL(flatten_kernel, dim3(cmbpo_ceil_div(r->B, kFlatRows)), dim3(256), lds, (hipStream_t)stream,
-                     *r, d_offsets, d_stats, fa);
+  hipStream_t s = (hipStream_t)stream;
+  const int dmax = r->obs_dim > r->act_dim ? r->obs_dim : r->act_dim;
+  // branches per workgroup of the vector fields: as many as keep the [branch][step][dim] tile within 64 KB (two
+  // workgroups per CU), 16 at AntSafe shapes and 34 steps
+  static const int vt_max = getenv("CMBPO_FLAT_VT") ? atoi(getenv("CMBPO_FLAT_VT")) : kVecTile;
+  int vt = vt_max < 1 ? 1 : (vt_max > kVecTile ? kVecTile : vt_max);
+  const int dtile = dmax > 3 * r->act_dim ? dmax : 3 * r->act_dim;     // obs alone, then act | log_std | mu side by side
+  while (vt > 1 && (size_t)vt * r->T * dtile * sizeof(float) > 64 * 1024) vt >>= 1;
+  const size_t lds_v = (size_t)vt * r->T * dtile * sizeof(float);
+  const size_t lds_s = (size_t)8 * kFlatRows * (r->T + 1) * sizeof(float) + (size_t)kFlatRows * r->T * sizeof(unsigned short);
+  CMBPO_REQUIRE(lds_v <= 150 * 1024 && lds_s <= 150 * 1024, "cmbpo_buffer_flatten: T = %d, dim = %d exceed the LDS tiles", r->T, dmax);
+  static size_t attr_v = 64 * 1024, attr_s = 64 * 1024;
+  if (lds_v > attr_v) {
+    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(flatten_vec_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v));
+    attr_v = lds_v;
+  }
+  if (lds_s > attr_s) {
+    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(flatten_scalar_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+    attr_s = lds_s;
+  }
+  hipLaunchKernelGGL(flatten_vec_kernel, dim3(cmbpo_ceil_div(r->B, vt)), dim3(256), lds_v, s, *r, d_offsets, fa, vt);
+  hipLaunchKernelGGL(flatten_scalar_kernel, dim3(cmbpo_ceil_div(r->B, kFlatRows)), dim3(256), lds_s, s, *r, d_offsets, d_stats, fa);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }

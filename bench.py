@@ -163,14 +163,108 @@ def build_hip(w, task, B, device, comm=None, maxroll=MAXROLL, mode="schedule"):
     return sampler, pool, env, policy
 
 
-def rollout_phase(sampler, pool, start):
+def rollout_phase(sampler, pool, start, max_samples=None):
     """reset -> sample until everything is finished -> finish_all_paths -> get(); returns samples."""
     sampler.reset(start)
-    while sampler.any_alive():
-        sampler.sample()
+    while sampler.any_alive() and pool.has_room:
+        sampler.sample(max_samples=max_samples)
     diag = sampler.finish_all_paths()
     res, bdiag = pool.get(as_tensors=True)
     return int(diag["msampler/samples_added"]), res
+
+
+def ens_flops_per_row(w):
+    D, A, E, H = w["obs_dim"], w["act_dim"], w["ws"][0].shape[0], w["ws"][1].shape[1]
+    return 2.0 * E * ((D + A) * H + H * H + H * 2 * (D + 1))
+
+
+def ens_roofline(w, events):
+    """Roofline entry of the dominant kernel (the fused ensemble forward) from HIP events on its launch stream.
+    `achieved` = ALGORITHMIC float32 flops per second; the peak is that of the matrix path the launches took."""
+    from cmbpo_amd import _lib
+    H = w["ws"][1].shape[1]
+    k_ms = [s.elapsed_time(e) for s, e, _ in events]
+    k_rows = [n for _, _, n in events]
+    if not k_ms:
+        return None
+    flop_row = ens_flops_per_row(w)
+    achieved = flop_row * float(np.sum(k_rows)) / (float(np.sum(k_ms)) * 1e-3) / 1e12
+    path = _lib.lib().cmbpo_get_ens_matrix_path() if H == 512 else 0
+    if path == 2 and float(np.mean(k_rows)) < 1536:     # cmbpo_set_ens_f16_min_rows default: small calls take the bf16 kernel
+        path = 1
+    peak, basis, kernel = {
+        0: (PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA dense 157.3 TFLOP/s", "ens_mlp_kernel<512,*,swish,prob>"),
+        1: (PEAK_BF16_MFMA_TFLOPS / 6, "bf16 dense 2500 TFLOP/s / 6 MFMAs per f32 product",
+            "ens_split_kernel (6 x v_mfma_f32_32x32x16_bf16 per f32 product)"),
+        2: (PEAK_BF16_MFMA_TFLOPS / 3, "f16 dense 2500 TFLOP/s / 3 MFMAs per f32 product",
+            "ens_h3_kernel (3 x v_mfma_f32_32x32x16_f16 per f32 product)"),
+    }[path]
+    return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "kernel": kernel, "avg_launch_ms": float(np.mean(k_ms)), "avg_rows_per_launch": float(np.mean(k_rows)),
+            "launches": len(k_ms), "flop_per_branch_step": flop_row, "peak_basis": basis,
+            # executed matrix flops over the dense f16 / bf16 peak: how busy the matrix pipe is at nominal clock
+            "mfma_pipe_util": achieved * {0: 1.0, 1: 6.0, 2: 3.0}[path] / (PEAK_FP32_MFMA_TFLOPS if path == 0 else PEAK_BF16_MFMA_TFLOPS),
+            "vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+            "vs_r01_basis_bf16_over_6": achieved / (PEAK_BF16_MFMA_TFLOPS / 6)}
+
+
+def get_roofline(w, get_events):
+    """HBM entry of ModelBuffer.get(): the flatten kernels' algorithmic bytes (every stored float read once, written
+    once: SURVEY 8d, ~490 B per sample at AntSafe shapes) over their HIP-event time."""
+    if not get_events:
+        return None
+    D, A = w["obs_dim"], w["act_dim"]
+    per_sample = 2.0 * 4.0 * (D + 3 * A + 8)
+    fl_ms = [b.elapsed_time(c) for _, b, c, _ in get_events]
+    all_ms = [a.elapsed_time(c) for a, _, c, _ in get_events]
+    n = [k for _, _, _, k in get_events]
+    achieved = per_sample * float(np.sum(n)) / (float(np.sum(fl_ms)) * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "kernel": "flatten_vec_kernel + flatten_scalar_kernel", "flatten_us": float(np.mean(fl_ms)) * 1e3,
+            "get_us_offsets_to_flatten": float(np.mean(all_ms)) * 1e3, "bytes_per_sample": per_sample,
+            "samples": float(np.mean(n))}
+
+
+def run_config(name, task, B, maxroll, mode, device, reps=3, dkl_scale=0.6, budget_frac=0.75, seed=0):
+    """One sub-result of the bench line: a shipped configuration's rollout phase on this rank (no collectives)."""
+    from cmbpo_amd import synthetic
+    w = build_world(seed, task)
+    sampler, pool, env, policy = build_hip(w, task, B, device, None, maxroll, mode)
+    start = torch.from_numpy(synthetic.start_states(np.random.default_rng(100), B, task)).to(device)
+    max_samples, lim = None, None
+    if mode == "uncertainty":
+        # the DKL limit calibrated like the trainer's (algorithms/cmbpo.py:197-199), tightened so that branches die of
+        # uncertainty along the rollout, and a sample budget that the early-termination rule has to enforce
+        # (samplers/model_sampler.py:275-287)
+        sampler.reset(start)
+        lim = float(sampler.compute_dynamics_dkl(start[: min(B, 5000)], depth=5)) * dkl_scale
+        sampler.set_rollout_dkl(lim)
+        max_samples = int(budget_frac * B * (maxroll - 1))
+    rollout_phase(sampler, pool, start, max_samples)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    samples = 0
+    for _ in range(reps):
+        n, _ = rollout_phase(sampler, pool, start, max_samples)
+        samples += n
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    env.kernel_events, pool.get_events = [], []      # one more phase through the instrumented (separate-call) path
+    steps_before = sampler._n_episodes if hasattr(sampler, "_n_episodes") else 0
+    rollout_phase(sampler, pool, start, max_samples)
+    torch.cuda.synchronize()
+    n_steps = sampler._n_episodes
+    out = {"name": name, "task": task, "branches": B, "maxroll": maxroll, "rollout_mode": mode,
+           "value": samples / dt, "unit": "imagined env-steps/s", "ms_per_phase": dt / reps * 1e3,
+           "samples_per_phase": samples / reps, "steps_per_phase": n_steps,
+           "us_per_step": dt / reps / max(n_steps, 1) * 1e6,
+           "roofline": ens_roofline(w, env.kernel_events), "gae_get": get_roofline(w, pool.get_events)}
+    if mode == "uncertainty":
+        out.update(dkl_lim=lim, max_samples=max_samples)
+    env.kernel_events, pool.get_events = None, None
+    del sampler, pool, env, policy
+    torch.cuda.empty_cache()
+    return out
 
 
 def time_update(policy, res, n, reps=3):
@@ -232,7 +326,7 @@ def cpu_train_baseline(E, I, H, O, loss, batch):
 def cpu_update_baseline(w, res, n):
     """One CPO update of the oracle (torch-CPU autograd graph + update_pi) on n samples; ms."""
     from oracle import refupdate
-    host = [x[:n].cpu().numpy() for x in res]
+    host = [x[:n].cpu().numpy() if hasattr(x, "cpu") else np.asarray(x[:n]) for x in res]
     obs, act, adv, cadv, _, _, logp, _, _, cost, ls, mu = host
     D, A = w["obs_dim"], w["act_dim"]
     graph = refupdate.PolicyGraph(D, A, dict(obs=obs, act=act, adv=adv, cadv=cadv, logp_old=logp, cost=cost,
@@ -252,40 +346,74 @@ def cpu_update_baseline(w, res, n):
     return (time.perf_counter() - t0) * 1e3
 
 
-def cpu_baseline(w, task, seconds=20.0):
-    """The oracle (NumPy restatement of the reference semantics, NOT TF 1.14) on the host cores."""
+def host_threads():
+    """Threads the CPU baselines run on: the cores this process may use (a GPU box hands a job a share of its cores;
+    BLAS pools sized for the whole machine oversubscribe that share several times over)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:        # cgroup v2 CPU quota, if any
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        pass
+    n = max(1, min(n, int(os.environ.get("CMBPO_CPU_THREADS", 16))))     # a one-GPU box's share of the host is 16 cores
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=n)
+    except Exception:
+        pass
+    torch.set_num_threads(n)
+    return n
+
+
+def cpu_baseline(w, task, seconds=20.0, runs=5):
+    """The oracle (NumPy restatement of the reference semantics, NOT TF 1.14) on the host cores: median of `runs`
+    bounded rollout phases (B = 2000 branches x 6 steps + finish / get each), plus one step of the full 100 000-branch
+    workload."""
     from oracle import refcpu
     from cmbpo_amd import synthetic
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    rng = np.random.default_rng(1)
-    B = 2000
+    threads = host_threads()
     model = lambda x: refcpu.ens_forward(x, w["ws"], w["bs"], w["sc_in"], w["sc_out"])
     policy = lambda obs, eps: refcpu.policy_forward(obs, w["pol"], eps)
     v = lambda obs: refcpu.ens_predict_mean(obs, *w["v"])[:, 0]
     vc = lambda obs: refcpu.ens_predict_mean(obs, *w["vc"])[:, 0]
-    orc = refcpu.RolloutOracle(model, policy, v, vc, task, w["obs_dim"], w["act_dim"], MAXROLL, "schedule",
-                               float("inf"))
-    start = synthetic.start_states(rng, B, task)
     elites = np.asarray(w["elites"], np.int32)
-    t0 = time.perf_counter()
-    orc.reset(start)
-    steps = 0
-    with np.errstate(all="ignore"):
-        while orc.alive.any() and (time.perf_counter() - t0 < seconds or steps < 2):
-            n = int(orc.alive.sum())
-            orc.sample(rng.standard_normal((n, w["act_dim"])).astype(np.float32),
-                       elites[rng.integers(0, len(elites), n)])
-            steps += 1
-        orc.finish_all()
-        orc.get()
-    dt = time.perf_counter() - t0
-    return dict(value=orc.tot["samples"] / dt, unit="imagined env-steps/s", cores=int(threads), kind="port",
-                sample=f"NumPy oracle (restatement of reference semantics, not TF 1.14): B={B} branches x "
-                       f"{steps} steps of the same workload + finish/get, {dt:.1f} s")
+
+    def phase(B, horizon, seed):
+        rng = np.random.default_rng(seed)
+        orc = refcpu.RolloutOracle(model, policy, v, vc, task, w["obs_dim"], w["act_dim"], horizon + 1, "schedule",
+                                   float("inf"))
+        start = synthetic.start_states(rng, B, task)
+        t0 = time.perf_counter()
+        orc.reset(start)
+        steps = 0
+        with np.errstate(all="ignore"):
+            while orc.alive.any():
+                n = int(orc.alive.sum())
+                orc.sample(rng.standard_normal((n, w["act_dim"])).astype(np.float32),
+                           elites[rng.integers(0, len(elites), n)])
+                steps += 1
+            orc.finish_all()
+            orc.get()
+        return orc.tot["samples"] / (time.perf_counter() - t0), steps
+
+    B, H = 2000, 6
+    phase(B, 2, 0)                                   # warm-up (BLAS threads, page faults)
+    rates, t_begin = [], time.perf_counter()
+    for r in range(runs):
+        rates.append(phase(B, H, 1 + r)[0])
+    dt = time.perf_counter() - t_begin
+    t1 = time.perf_counter()
+    rate_full, _ = phase(100000, 1, 99)              # one step + finish / get of the headline batch
+    dt_full = time.perf_counter() - t1
+    return dict(value=float(np.median(rates)), unit="imagined env-steps/s", cores=int(threads), kind="port",
+                runs=[float(x) for x in rates], value_b100k_one_step=float(rate_full),
+                sample=f"NumPy oracle (restatement of reference semantics, not TF 1.14), {int(threads)} threads: median of "
+                       f"{runs} phases of B={B} branches x {H} steps of the same workload + finish/get ({dt:.1f} s in all); "
+                       f"value_b100k_one_step = one step + finish/get at B=100000 ({dt_full:.1f} s)")
 
 
 def dry_run(args):
@@ -347,7 +475,7 @@ def main():
 
     for _ in range(args.warmup):
         rollout_phase(sampler, pool, start)
-    env.kernel_events = []
+    env.kernel_events, pool.get_events = [], []
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -359,57 +487,79 @@ def main():
     comm.barrier()
     dt = time.perf_counter() - t0
     events, env.kernel_events = env.kernel_events, None
-
-    extras = not args.no_extras
-    # Metric B: CPO trust-region update (update_policy, algorithms/cmbpo.py:357) on the rollout's samples
-    _, res = rollout_phase(sampler, pool, start)
-    n_full = int(res[0].shape[0])
-    n50 = min(50000, n_full)
-    upd_ms_50k, upd_info = time_update(policy, res, n50)
-    upd_ms_full, _ = time_update(policy, res, n_full, reps=2)
-
-    # Metric C: ensemble training steps (dynamics model on (obs, act) -> (d_obs, rew); critic on obs -> ret)
-    obs_t, act_t, ret_t = res[0], res[1], res[4]
-    n_tr = min(n_full, 200000)
-    x_dyn = torch.cat([obs_t[:n_tr], act_t[:n_tr]], dim=1).contiguous()
-    t_dyn = torch.cat([0.01 * torch.randn_like(obs_t[:n_tr]), ret_t[:n_tr, None]], dim=1).contiguous()
-    model_us = time_train_steps(env._model, x_dyn, t_dyn, 2048, 100)
-    critic_us = time_train_steps(policy.v, obs_t[:n_tr].contiguous(), ret_t[:n_tr, None].contiguous(), 2048, 300)
+    get_events, pool.get_events = pool.get_events, None
 
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     comm.all_reduce_max(t)
     dt_max = float(t.item())
     tot = comm.all_reduce_host([samples])[0]
 
-    # roofline of the dominant kernel (fused ensemble MLP forward), HIP events on the launch stream
+    extras = not args.no_extras
+    upd, train, subs = None, None, []
     D, A, E, H = w["obs_dim"], w["act_dim"], w["ws"][0].shape[0], w["ws"][1].shape[1]
-    flop_per_row = 2.0 * E * ((D + A) * H + H * H + H * 2 * (D + 1))
-    k_ms = [s.elapsed_time(e) for s, e, _ in events]
-    k_rows = [n for _, _, n in events]
-    avg_ms = float(np.mean(k_ms)) if k_ms else float("nan")
-    achieved = flop_per_row * float(np.mean(k_rows)) / (avg_ms * 1e-3) / 1e12 if k_ms else float("nan")
+    if extras:
+        # Metric B: CPO trust-region update (update_policy, algorithms/cmbpo.py:357) on the rollout's samples
+        _, res = rollout_phase(sampler, pool, start)
+        n_full = int(res[0].shape[0])
+        n50 = min(50000, n_full)
+        upd_ms_50k, upd_info = time_update(policy, res, n50)
+        upd_ms_full, _ = time_update(policy, res, n_full, reps=2)
+        upd = {"unit": "ms", "n_50k": n50, "ms_50k": upd_ms_50k, "n_full": n_full, "ms_full": upd_ms_full,
+               "optim_case": int(upd_info["OptimCase"]), "hvps": int(upd_info["n_fvp"]), "per_rank": True}
+        # Metric C: ensemble training steps (dynamics model on (obs, act) -> (d_obs, rew); critic on obs -> ret)
+        obs_t, act_t, ret_t = res[0], res[1], res[4]
+        n_tr = min(n_full, 200000)
+        x_dyn = torch.cat([obs_t[:n_tr], act_t[:n_tr]], dim=1).contiguous()
+        t_dyn = torch.cat([0.01 * torch.randn_like(obs_t[:n_tr]), ret_t[:n_tr, None]], dim=1).contiguous()
+        model_us = time_train_steps(env._model, x_dyn, t_dyn, 2048, 100)
+        critic_us = time_train_steps(policy.v, obs_t[:n_tr].contiguous(), ret_t[:n_tr, None].contiguous(), 2048, 300)
+        fl_model = 6.0 * E * 2048 * ((D + A) * H + H * H + H * 2 * (D + 1))
+        train = {"unit": "us/step", "batch": 2048, "model_step_us": model_us, "model_tflops": fl_model / model_us / 1e6,
+                 "critic_step_us": critic_us, "model": f"E={E} {D + A}->{H}->{H}->{2 * (D + 1)} MSPE + Adam",
+                 "critic": "E=3 obs->128->128->1 MSE + Adam", "per_rank": True}
+        res_host = [x[:n50].cpu() for x in res]       # for the CPU update baseline, before the buffers are released
+        del res, obs_t, act_t, ret_t, x_dyn, t_dyn
 
-    # which matrix path ran: fp32 MFMAs, or float32 products carried by six bf16 MFMAs each (same float32 results
-    # within rounding, same parity tests).  The roofline of the latter is the bf16 dense peak divided by the six
-    # MFMAs a float32 product costs; `achieved` stays the ALGORITHMIC float32 flops per second either way.
-    from cmbpo_amd import _lib
-    split = H == 512 and _lib.lib().cmbpo_get_ens_matrix_path() == 1
-    peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS if split else PEAK_FP32_MFMA_TFLOPS
-    kernel_name = "ens_split_kernel (6 x v_mfma_f32_32x32x16_bf16 per f32 product)" if split else "ens_mlp_kernel<512,1,swish,prob>"
-    pmc_file = "pmc_traffic_split.json" if split else "pmc_traffic.json"
+    roof = ens_roofline(w, events)
+    # HBM traffic of the dominant kernel from PMC counters collected OFFLINE (separate rocprofv3 --pmc passes, see the
+    # json file), scaled to this run's rows per launch -- not a measurement of this run
+    pmc_file = {"ens_h3": ("r02", "pmc_traffic_h3.json"), "ens_split": ("r01", "pmc_traffic_split.json"),
+                "ens_mlp": ("r01", "pmc_traffic.json")}[roof["kernel"].split("_kernel")[0]] if roof else None
+    if roof is not None:
+        roof["traffic"] = None
+        roof["traffic_offline_pmc"] = None
+        try:
+            with open(os.path.join(ROOT, "profiles", pmc_file[0], pmc_file[1])) as f:
+                pmc = json.load(f)
+            if task == "AntSafe-v2":
+                roof["traffic_offline_pmc"] = pmc["hbm_bytes_per_launch"] * roof["avg_rows_per_launch"] / pmc["rows_per_launch"]
+                roof["traffic"] = roof["traffic_offline_pmc"]
+                roof["traffic_source"] = f"profiles/{pmc_file[0]}/{pmc_file[1]} (offline rocprofv3 --pmc passes, scaled by rows)"
+        except Exception:
+            pass
 
-    # HBM traffic of the dominant kernel: PMC counters collected offline (separate rocprofv3 --pmc passes, see
-    # profiles/r01/pmc_traffic.json), scaled to this run's rows per launch
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01", pmc_file)) as f:
-            pmc = json.load(f)
-        if task == "AntSafe-v2" and k_rows:
-            traffic = pmc["hbm_bytes_per_launch"] * float(np.mean(k_rows)) / pmc["rows_per_launch"]
-    except Exception:
-        traffic = None
+    if extras and world == 1 and rank == 0:
+        # what ships: the rollout phase at the shipped configurations' shapes and modes (configs/cmbpo_hcs.py:17-31,
+        # configs/cmbpo_hs.py:5,28, configs/cmbpo_antsafe.py:33; budget rule samplers/model_sampler.py:275-287)
+        del sampler, pool, env
+        torch.cuda.empty_cache()
+        for spec in (("hcs_b10k", "HalfCheetahSafe-v2", 10000, 35, "schedule"),
+                     ("humanoid_b10k_h14", "HumanoidSafe-v2", 10000, 15, "schedule"),
+                     ("hopper_b10k_h14", "HopperSafe-v2", 10000, 15, "schedule"),
+                     ("antsafe_b1000", "AntSafe-v2", 1000, 35, "schedule"),
+                     ("antsafe_b1000_uncertainty_budget", "AntSafe-v2", 1000, 35, "uncertainty"),
+                     ("antsafe_b100k_uncertainty_budget", "AntSafe-v2", 100000, 35, "uncertainty")):
+            subs.append(run_config(*spec, device))
 
     if rank == 0:
+        arith = {
+            "ens_h3": ("float32 inputs, outputs and accumulation; each float32 product of the ensemble forward runs as three exact "
+                       "f16 partial products (operands lifted by a power of two and split exactly into 2 f16 pieces, 11 + 1 + 11 "
+                       "significant bits; measured error 3.2e-7 of sum|a_k b_k| at K = 512 against 7.6e-7 for the fp32 MFMA chain, "
+                       "tools/split_f16_probe.hip); cmbpo_set_ens_matrix_path(1) selects six bf16 terms, (0) fp32 MFMAs"),
+            "ens_split": ("float32 inputs, outputs and accumulation; the ensemble forward's float32 products run as six exact bf16 "
+                          "partial products each (operands split exactly into 3 bf16 pieces)"),
+            "ens_mlp": "float32 throughout (fp32 MFMAs)"}[roof["kernel"].split("_kernel")[0]] if roof else None
         out = {
             "metric": "imagined env-steps/sec (ensemble rollout) + CPO update ms",
             "value": tot / dt_max,
@@ -427,35 +577,22 @@ def main():
                                    f"3+3 critics 128x128, tanh policy 128x128, "
                                    + (f"B={args.branches} branches sharded over {world} GPU(s)" if args.scaling == "strong"
                                       else f"B={B} branches/GPU")
-                                   + f", maxroll {maxroll} ({maxroll - 1} steps), reset->sample*->finish_all_paths->get()",
+                                   + f", maxroll {maxroll} ({maxroll - 1} steps), fixed-horizon mode, "
+                                     f"reset->sample*->finish_all_paths->get()",
                        "branches_per_gpu": B, "branches_total": args.branches if args.scaling == "strong" else B * world,
-                       "horizon": maxroll - 1, "task": task,
-                       "samples_per_step": tot / args.steps,
-                       "arithmetic": ("float32 inputs, outputs and accumulation; the ensemble forward's float32 products run as six "
-                                      "exact bf16 partial products each (operands split exactly into 3 bf16 pieces; measured error "
-                                      "6.2e-7 of sum|a_k b_k| at K = 512 against 7.6e-7 for the fp32 MFMA chain); "
-                                      "cmbpo_set_ens_matrix_path(0) / CMBPO_ENS_SPLIT=0 selects fp32 MFMAs") if split else
-                                     "float32 throughout (fp32 MFMAs)"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
-                         "kernel": kernel_name, "avg_launch_ms": avg_ms,
-                         "launches": len(k_ms), "flop_per_branch_step": flop_per_row,
-                         "peak_basis": ("bf16 dense 2500 TFLOP/s / 6 MFMAs per f32 product" if split
-                                        else "fp32 MFMA dense 157.3 TFLOP/s"),
-                         "vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS},
+                       "horizon": maxroll - 1, "task": task, "samples_per_step": tot / args.steps, "arithmetic": arith},
+            "roofline": roof,
+            "gae_get": get_roofline(w, get_events),
         }
-        out["cpo_update"] = {"unit": "ms", "n_50k": n50, "ms_50k": upd_ms_50k, "n_full": n_full,
-                             "ms_full": upd_ms_full, "optim_case": int(upd_info["OptimCase"]),
-                             "hvps": int(upd_info["n_fvp"]), "per_rank": True}
-        fl_model = 6.0 * E * 2048 * ((D + A) * H + H * H + H * 2 * (D + 1))
-        out["ensemble_train"] = {"unit": "us/step", "batch": 2048, "model_step_us": model_us,
-                                 "model_tflops": fl_model / model_us / 1e6, "critic_step_us": critic_us,
-                                 "model": f"E={E} {D + A}->{H}->{H}->{2 * (D + 1)} MSPE + Adam",
-                                 "critic": "E=3 obs->128->128->1 MSE + Adam", "per_rank": True}
-        if not args.no_cpu_baseline and world == 1:     # the CPU baseline is timed at N = 1 only
+        if upd is not None:
+            out["cpo_update"] = upd
+            out["ensemble_train"] = train
+        if subs:
+            out["configs"] = subs
+        if extras and not args.no_cpu_baseline and world == 1:     # the CPU baseline is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(w, task, seconds=args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-            out["cpu_baseline"]["cpo_update_ms_50k"] = cpu_update_baseline(w, res, n50)
+            out["cpu_baseline"]["cpo_update_ms_50k"] = cpu_update_baseline(w, res_host, n50)
             out["cpu_baseline"]["model_train_step_us"] = cpu_train_baseline(E, D + A, H, 2 * (D + 1), "MSPE", 2048)
             out["cpu_baseline"]["critic_train_step_us"] = cpu_train_baseline(3, D, 128, 1, "MSE", 2048)
         print(json.dumps(out), flush=True)

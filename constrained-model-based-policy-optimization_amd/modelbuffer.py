@@ -214,6 +214,11 @@ class ModelBuffer:
         self.sync_counters()
         assert self._n_alive == 0, "all paths have to be finished"          # modelbuffer.py:194
         t = self.t
+        ev = None
+        if getattr(self, "get_events", None) is not None:    # bench.py: HIP events around get()'s kernels
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+                  torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         self._call("cmbpo_buffer_offsets", t["offsets"].data_ptr())
         self._call("cmbpo_buffer_moments", 0, t["stats"].data_ptr())
         if self.comm is not None and self.comm.world > 1:
@@ -230,7 +235,12 @@ class ModelBuffer:
         outs = [torch.empty((n, d) if d else (n,), **f) for d in dims]
         if n > 0:
             ptrs = (C.c_void_p * 12)(*[o.data_ptr() for o in outs])
+            if ev is not None:
+                ev[1].record()
             self._call("cmbpo_buffer_flatten", t["offsets"].data_ptr(), t["stats"].data_ptr(), ptrs)
+            if ev is not None:
+                ev[2].record()
+                self.get_events.append((ev[0], ev[1], ev[2], n))
             st = t["stats"].cpu().numpy()
             ret_mean, cret_mean = float(st[4]), float(st[5])
         else:

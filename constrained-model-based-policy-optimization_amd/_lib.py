@@ -116,6 +116,7 @@ SIGNATURES.update({
     "cmbpo_pi_cg_iter": (_i, [_p, _bp, C.c_double, C.c_float, _p, _p, _p, _p, _p]),
     "cmbpo_pi_cg_commit": (_i, [_p, _p]),
     "cmbpo_pi_cg_graph_launches": (C.c_long, []),
+    "cmbpo_pi_cg_graph_captures": (C.c_long, []),
     "cmbpo_vec_lincomb": (_i, [_i, C.c_float, _p, C.c_float, _p, _p, _p]),
     "cmbpo_vec_dots": (_i, [_i, _i, C.POINTER(_p), C.POINTER(_p), _p, _p]),
     "cmbpo_gae_segments": (_i, [_i] + [_p] * 8 + [C.c_double] * 4 + [_p] * 5),

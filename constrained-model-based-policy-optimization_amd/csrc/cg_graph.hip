@@ -82,11 +82,12 @@ extern "C" int cmbpo_pi_cg_solve(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, const
       if (graph) (void)hipGraphDestroy(graph);
       if (!ok) {
         (void)hipGetLastError();
+        if (g_graph_ok) fprintf(stderr, "cmbpo_pi_cg_solve: stream capture failed, the CG solves stay on the eager loop\n");
         g_graph_ok = false;               // capture not available here: stay on the eager loop
         if (rc != CMBPO_OK) return rc;
       } else {
         CgGraph cg;
-        cg.key = k;
+        memcpy(&cg.key, &k, sizeof(k));   // byte copy: the cache check compares whole keys, padding bytes included
         cg.exec = exec;
         it = g_graphs.emplace(gk, cg).first;
         ++g_graph_captures;
@@ -117,3 +118,5 @@ extern "C" void cmbpo_pi_cg_release(cmbpo_pi_t *h) {
 
 // graph launches so far, or -1 when stream capture turned out to be unavailable (diagnostics / tests)
 extern "C" long cmbpo_pi_cg_graph_launches(void) { return g_graph_ok ? g_graph_launches : -1; }
+// graphs captured so far: stays at one per (handle, solution vector) while the arguments do not change
+extern "C" long cmbpo_pi_cg_graph_captures(void) { return g_graph_captures; }

@@ -48,6 +48,9 @@ __device__ float np_sum_f32(const float *a, int n) {
   return res;
 }
 
+// np.clip(x, lo, hi): comparisons are false for a NaN, which therefore passes through (fminf / fmaxf would drop it)
+__device__ __forceinline__ float clip_np(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
 __global__ __launch_bounds__(kThreads) void fakeenv_post_kernel(const PostArgs p) {
   extern __shared__ float sm[];
   const int D = p.obs_dim;
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(kThreads) void fakeenv_post_kernel(const PostArgs p
         const float v0 = p.var[e * mstride + base];
         float l = __fmul_rn(0.5f, logf(v0));
         const bool inside = l >= -100.0f && l <= 1e8f;       // false for NaN as well
-        if (!inside) l = fminf(fmaxf(logf(sqrtf(v0)), -100.0f), 1e8f);
+        if (!inside) l = clip_np(logf(sqrtf(v0)), -100.0f, 1e8f);   // np.clip: a NaN stays a NaN
         ls[e] = l;
         vr[e] = inside ? v0 : expf(__fmul_rn(2.0f, l));
       }
@@ -103,10 +106,11 @@ __global__ __launch_bounds__(kThreads) void fakeenv_post_kernel(const PostArgs p
         sq = __fadd_rn(sq, __fmul_rn(dlt, dlt));
       }
     s_var[i] = sq / (float)E;
-    // average KL over all ordered pairs (i outer, j inner), models/pens/utils.py:49-56.  Two exact savings: the a == c terms
-    // are 0.5 (v / (v + 1e-10) - 1) <= 0 (or NaN), which the clip turns into +0 -- adding +0 to the non-negative
-    // running sum changes nothing, so they are skipped; and (mu_c - mu_a)^2 == (mu_a - mu_c)^2 bit for bit, so the
-    // squared difference of a pair is computed once.
+    // average KL over all ordered pairs (i outer, j inner), models/pens/utils.py:49-56.  Two exact savings: an a == c term
+    // is 0.5 (v / (v + 1e-10) - 1) <= 0 for finite v and mu, which np.clip turns into +0 -- adding +0 to the
+    // non-negative running sum changes nothing, so those are skipped (for a member whose variance is inf / NaN or whose
+    // mean is non-finite the term is NaN, np.clip keeps it, and the reference's KL of that branch is NaN: added below); and
+    // (mu_c - mu_a)^2 == (mu_a - mu_c)^2 bit for bit, so the squared difference of a pair is computed once.
     float dm2[kEMax][kEMax];
 #pragma unroll
     for (int a = 0; a < kEMax; ++a)
@@ -134,10 +138,12 @@ __global__ __launch_bounds__(kThreads) void fakeenv_post_kernel(const PostArgs p
             const float q = __fmul_rn(num, rden[c]);
             float pre = __fmul_rn(0.5f, __fsub_rn(q, 1.0f));
             pre = __fsub_rn(__fadd_rn(pre, ls[c]), ls[a]);
-            pre = fminf(fmaxf(pre, 0.0f), 1e10f);
+            pre = clip_np(pre, 0.0f, 1e10f);
             acc = __fadd_rn(acc, pre);
           }
         }
+        // the a == a term of a member with a non-finite variance or mean: (0 or NaN + v) / (v + 1e-10) is inf / inf or NaN
+        if (!isfinite(vr[a]) || !isfinite(mu[a])) acc = __fadd_rn(acc, __builtin_nanf(""));
       }
     }
     s_dkl[i] = acc / ((float)(E * (E - 1)) + 1e-10f);

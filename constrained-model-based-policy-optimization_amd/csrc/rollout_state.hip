@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kScanThreads) void decide_budget_kernel(const cmbpo
     r.iscal[11] = 0;
     r.iscal[CMBPO_I_N_FIN_PRE] = n_unc;
   }
-  if (count_only || r.max_samples <= 0) return;
+  if (count_only || r.max_samples == 0) return;    // `if max_samples:` -- a negative budget IS a budget (model_sampler.py:282)
   long long excess;
   int rank_off = 0;
   if (r.use_host_budget) {

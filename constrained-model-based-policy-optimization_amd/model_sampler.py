@@ -205,7 +205,7 @@ class ModelSampler:
             rs.dkl_lim = float(self.dkl_lim)
             rs.max_path_length = self._max_path_length
             rs.use_host_budget = 0
-            exchange = sharded and rs.max_samples > 0
+            exchange = sharded and rs.max_samples != 0      # the reference's `if max_samples:` (negative budgets count)
             if not exchange and env.kernel_events is None:
                 # the whole step in one call: at small rollout batches a step is bound by host latency
                 _lib.check(_lib.lib().cmbpo_rollout_step(

@@ -176,7 +176,8 @@ typedef struct cmbpo_rollout {
   int32_t ptr;              /* column of the next store (modelbuffer.py:135)   */
   int32_t uncertainty_mode; /* rollout_mode == 'uncertainty' (:275-279)        */
   int32_t rank, world;      /* shard id / count (budget rule offsets)          */
-  int64_t max_samples;      /* budget of sample(max_samples); <= 0: none       */
+  int64_t max_samples;      /* budget of sample(max_samples); 0: none (the reference tests `if max_samples:`, so a
+                             * negative budget early-terminates every surviving branch, model_sampler.py:282-287) */
   double dkl_lim;           /* set_rollout_dkl (:169-170)                      */
   double gamma, lam, cost_gamma, cost_lam; /* modelbuffer.py:41-51             */
   /* ordered alive list (ascending slot ids) and scalars */
@@ -390,6 +391,7 @@ int cmbpo_pi_cg_iter(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, double inv_n, flo
                      float *d_r, float *d_p, double *d_scal, void *stream);
 int cmbpo_pi_cg_commit(double *d_scal, void *stream);
 long cmbpo_pi_cg_graph_launches(void);   /* graph replays so far; -1: stream capture unavailable, eager loop in use */
+long cmbpo_pi_cg_graph_captures(void);   /* graphs captured so far: one per (handle, solution vector) while the arguments repeat */
 /* d_out = a * d_x + b * d_y (d_y may be NULL): Hx = hvp / N + damping v, the step x = (v + nu w) / (lam + eps)
  * (policies/cpo_policy.py:266) and the trial parameters old - step * x (:278). */
 int cmbpo_vec_lincomb(int P, float a, const float *d_x, float b, const float *d_y, float *d_out, void *stream);

@@ -357,6 +357,7 @@ def main():
     gen_pe_train(HERE)
     gen_loop_helpers(HERE)
     gen_cpobuffer_archive(HERE)
+    gen_cpo_sampler(HERE)
     print("golden vectors written to", HERE)
 
 
@@ -698,8 +699,43 @@ def gen_cpobuffer_archive(out):
     print("cpobuffer archive:", buf.arch_size, "samples, epochs", list(buf.epochs_list))
 
 
+# ------------------------------------------------------------------------------------------------
+# G12: the reference's real-environment sampler (samplers/cpo_sampler.py:125-235) + CPOBuffer, driven by a scripted toy
+# environment and a stub policy (tests/toyworld.py): what it hands to its buffer, what it logs, and the buffer's get()
+# ------------------------------------------------------------------------------------------------
+def gen_cpo_sampler(out):
+    sys.path.insert(0, os.path.dirname(HERE))
+    import toyworld
+    from samplers.cpo_sampler import CpoSampler
+    from buffers.cpobuffer import CPOBuffer
+    data = {}
+    # (a) against a recording pool: the exact store() / finish_path() call sequence
+    pool = toyworld.RecordingPool()
+    res = toyworld.drive(CpoSampler, pool)
+    data["stores"] = np.array(pool.stores)
+    data["finishes"] = np.array(pool.finishes)
+    for k, v in res.items():
+        data["rec_" + k] = v
+    # (b) into the reference's own CPOBuffer: the 12-array list of get()
+    D, A = toyworld.ToyEnv.D, toyworld.ToyEnv.A
+    buf = CPOBuffer(size=128, archive_size=512, observation_space=_Space(D), action_space=_Space(A))
+    buf.initialize({"mu": [A], "log_std": [A]}, gamma=0.99, lam=0.95, cost_gamma=0.97, cost_lam=0.5)
+    res2 = toyworld.drive(CpoSampler, buf)
+    got, diag = buf.get()
+    names = ["obs", "act", "adv", "cadv", "ret", "cret", "logp", "val", "cval", "cost", "log_std", "mu"]
+    for k, v in zip(names, got):
+        data["get_" + k] = v
+    data["poolr_ret_mean"], data["poolr_cret_mean"] = diag["poolr_ret_mean"], diag["poolr_cret_mean"]
+    assert np.array_equal(res2["rets"], res["rets"])
+    np.savez_compressed(os.path.join(out, "g12_cpo_sampler.npz"), **data)
+    print("cpo sampler:", len(pool.stores), "stores,", len(pool.finishes), "finished paths, episodes", res["n_episodes"])
+
+
 if __name__ == "__main__":
-    if "--traces-only" in sys.argv:
+    if "--cpo-sampler-only" in sys.argv:
+        install_stubs()
+        gen_cpo_sampler(HERE)
+    elif "--traces-only" in sys.argv:
         install_stubs()
         gen_sampler_traces(HERE)
     elif "--archive-only" in sys.argv:

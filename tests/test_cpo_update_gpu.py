@@ -165,6 +165,16 @@ def test_cg_solve_graph_matches_eager_loop(hip_lib):
     np.testing.assert_array_equal(outs[0], outs[1])        # same kernels, same order: bitwise equal
     np.testing.assert_array_equal(outs[0], outs[2])
     assert _lib.lib().cmbpo_pi_cg_graph_launches() >= 2    # capture is available on this stack and was replayed
+    # repeated solves with the same buffers replay ONE captured graph (the cache key compares equal: no re-capture)
+    ops.use_graph = True
+    x = torch.zeros_like(b)
+    ops.cg_dev(b, x, 0.1)
+    caps = _lib.lib().cmbpo_pi_cg_graph_captures()
+    for _ in range(3):
+        x.zero_()
+        ops.cg_dev(b, x, 0.1)
+    assert _lib.lib().cmbpo_pi_cg_graph_captures() == caps
+    np.testing.assert_array_equal(x.cpu().numpy(), outs[0])
     # and it is the CG of the oracle's operator
     ref = refupdate.cg(lambda v: graph.hvp(params, v, 0.1), b.cpu().numpy()) if hasattr(refupdate, "cg") else None
     if ref is not None:

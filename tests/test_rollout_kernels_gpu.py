@@ -186,6 +186,12 @@ def test_fakeenv_post_matches_oracle(hip_lib, task, n):
         mean[:, 3, 4] = np.nan    # non-finite, z_rot finite -> gate 0 -> not done
         mean[:, 4, 2] = np.inf    # z_rot = -inf, gate 0 -> 0 * -inf = nan -> done
         mean[:, 5, -2] = 10.0     # |y| > 3.2 -> cost 1 (obs slot is out_dim-2 = obs_dim-1)
+    if n > 8:
+        # members with an unbounded / undefined variance or a NaN mean: np.clip keeps the NaN of their own (i == i) KL
+        # term, so the reference's KL of the branch is NaN (and `NaN >= dkl_lim` keeps the branch alive): same here
+        var[1, 6, 3] = np.inf
+        var[0, 7, 1] = np.nan
+        mean[2, 8, 5] = np.nan
     got = _run_post(task, obs, act, mean, var, inds, obs_dim, act_dim)
     with np.errstate(all="ignore"):
         rn, rr, rt, info = refcpu.fake_env_step(obs, act, mean, var, inds, task)
@@ -194,6 +200,10 @@ def test_fakeenv_post_matches_oracle(hip_lib, task, n):
     np.testing.assert_array_equal(got["term"].astype(bool), rt[:, 0])        # bit-exact masks
     np.testing.assert_array_equal(got["cost"], np.asarray(info["cost"], np.float32)[:, 0])
     ok = np.isfinite(info["ensemble_dkl_path"])
+    np.testing.assert_array_equal(np.isnan(got["dkl_path"]), np.isnan(info["ensemble_dkl_path"]))   # NaN where the reference's is
+    np.testing.assert_array_equal(np.isinf(got["dkl_path"]), np.isinf(info["ensemble_dkl_path"]))
+    if n > 8:
+        assert np.isnan(got["dkl_path"][[6, 7, 8]]).all()
     np.testing.assert_allclose(got["dkl_path"][ok], info["ensemble_dkl_path"][ok], rtol=1e-4, atol=1e-7)
     evar = info["ensemble_ep_var"]
     okv = np.isfinite(evar)

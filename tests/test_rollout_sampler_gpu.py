@@ -119,6 +119,7 @@ def _oracle(w, task, T, mode, lim):
     ("AntSafe-v2", 1500, 10, 512, None),        # the production dynamics width, terminations + horizon
     ("HumanoidSafe-v2", 333, 6, 128, 1500),     # wide obs/act (3 output tiles), budget, no statics entry
     ("HalfCheetahSafe-v2", 2048, 5, 128, None),
+    ("HalfCheetahSafe-v2", 300, 5, 128, -100),  # `if max_samples:` is true for a negative budget: every survivor is finished
 ])
 def test_hip_sampler_matches_oracle_on_fresh_seeds(hip_lib, task, B, T, hidden, budget):
     _need_gpu()

@@ -190,8 +190,6 @@ def ens_roofline(w, events):
     flop_row = ens_flops_per_row(w)
     achieved = flop_row * float(np.sum(k_rows)) / (float(np.sum(k_ms)) * 1e-3) / 1e12
     path = _lib.lib().cmbpo_get_ens_matrix_path() if H == 512 else 0
-    if path == 2 and float(np.mean(k_rows)) < 1536:     # cmbpo_set_ens_f16_min_rows default: small calls take the bf16 kernel
-        path = 1
     peak, basis, kernel = {
         0: (PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA dense 157.3 TFLOP/s", "ens_mlp_kernel<512,*,swish,prob>"),
         1: (PEAK_BF16_MFMA_TFLOPS / 6, "bf16 dense 2500 TFLOP/s / 6 MFMAs per f32 product",

@@ -39,6 +39,7 @@ SIGNATURES = {
     "cmbpo_set_ens_matrix_path": (_i, [_i]),
     "cmbpo_get_ens_matrix_path": (_i, []),
     "cmbpo_set_ens_f16_min_rows": (_i, [_i]),
+    "cmbpo_set_ens_f16_row_tiles": (_i, [_i]),
     "cmbpo_mlp_create": (_i, [C.POINTER(_p), _i, _i, _i, _i, _i, _i]),
     "cmbpo_mlp_destroy": (None, [_p]),
     "cmbpo_mlp_load": (_i, [_p] * 13),

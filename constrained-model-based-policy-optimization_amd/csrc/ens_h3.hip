@@ -44,31 +44,42 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThreadsH = 512;
 constexpr int kWavesH = 8;
 constexpr int HIDH = 512;
-constexpr int RT = 4;                 // 32-row tiles per item
-constexpr int ROWSH = 32 * RT;        // 128
-constexpr int NTC = 8 / RT;           // hidden n-tiles per chunk (one (n-tile, row-tile) pair per wave)
-constexpr int CK = 32 * NTC;          // hidden units per chunk
-constexpr int NCH = HIDH / CK;        // chunks
-constexpr int SLC = CK / 16;          // 16-deep slabs per chunk
-constexpr int CSTR = CK + 8;          // row stride (halves) of a chunk image: 16-B slots per row odd -> conflict-free
 constexpr int NSTAT = 12;             // floats per member in the stats block: {s, L1, B, -} x 3 layers
 
+// Geometry of an item of RT 32-row tiles (4: the throughput shape; 2 / 1: the same kernel for rollout batches too small
+// to give every CU a 128-row item -- an item's latency is the step's there).  Whatever RT, a chunk of h1 is 8 (n-tile,
+// row-tile) pairs = one per wave, and a step of the fused layer-0/1 loop is 16 (slab, row tile) positions of 6 MFMAs.
+template <int RT>
+struct Geo {
+  static constexpr int ROWS = 32 * RT;
+  static constexpr int NTC = 8 / RT;           // hidden n-tiles per chunk
+  static constexpr int CK = 32 * NTC;          // hidden units per chunk
+  static constexpr int NCH = HIDH / CK;        // chunks
+  static constexpr int SLC = CK / 16;          // 16-deep slabs per chunk
+  static constexpr int CSTR = CK + 8;          // row stride (halves) of a chunk image: 16-B slots per row odd -> conflict-free
+  static constexpr int TPR = kThreadsH / ROWS; // threads staging one input row
+  static constexpr int KPT = 64 / TPR;         // input elements per staging thread
+  static constexpr int DA = RT == 4 ? 2 : 4;   // ring of layer-1 weight fragments (slabs): DA - 1 slabs of lookahead
+  static constexpr int CBUF_BYTES = 2 * ROWS * CSTR * 2;          // one chunk image (both pieces)
+  static constexpr bool W0_LDS = RT == 4;      // W0 fragments shared by several waves pass through LDS
+};
+
 // ---- LDS map (bytes) ---------------------------------------------------------------------------------------------
-// [0, ...)            layers 0 / 1: chunk images [2][2 pieces][128][CSTR] | x image [2][128][XSTR] | W0 chunk [2][4 S0 KB]
+// [0, ...)            layers 0 / 1: chunk images [2][2 pieces][ROWS][CSTR] | x image [2][ROWS][XSTR] | W0 chunk [2][4 S0 KB]
 //                     tail (aliases the above): partial outputs [2][8 waves][2 tiles][16][64] f32 | staging [2][32][SWS]
 // [OFF_CONST, ...)    bias0 | bias1 | head constants | per-row scales | input scaler
-constexpr int CBUF_BYTES = 2 * ROWSH * CSTR * 2;          // one chunk image (both pieces)
 constexpr int PBUF_BYTES = kWavesH * 2 * 16 * 64 * 4;     // partial outputs of one unit: [8 waves][2 tiles][4][64 lanes] x 16 B
 constexpr int SWS = 65;                                   // row stride of a staging tile (floats): odd
 constexpr int STG_BYTES = 32 * SWS * 4;
-__host__ __device__ constexpr int ximg_bytes(int S0) { return 2 * ROWSH * (16 * S0 + 8) * 2; }
-__host__ __device__ constexpr int w0buf_bytes(int S0) { return NTC * S0 * 2 * 1024; }   // one chunk
-__host__ __device__ constexpr int off_const(int S0) {
-  const int a = 2 * CBUF_BYTES + ximg_bytes(S0) + 2 * w0buf_bytes(S0), b = 2 * PBUF_BYTES + 2 * STG_BYTES;
+__host__ __device__ constexpr int ximg_bytes(int S0, int RT) { return 2 * 32 * RT * (16 * S0 + 8) * 2; }
+__host__ __device__ constexpr int w0buf_bytes(int S0, int RT) { return RT == 4 ? 2 * S0 * 2 * 1024 : 0; }   // one chunk
+__host__ __device__ constexpr int off_const(int S0, int RT) {
+  const int cb = RT == 4 ? Geo<4>::CBUF_BYTES : (RT == 2 ? Geo<2>::CBUF_BYTES : Geo<1>::CBUF_BYTES);
+  const int a = 2 * cb + ximg_bytes(S0, RT) + 2 * w0buf_bytes(S0, RT), b = 2 * PBUF_BYTES + 2 * STG_BYTES;
   return ((a > b ? a : b) + 15) / 16 * 16;
 }
-constexpr int CONST_FLOATS = 2 * HIDH + 2 * 128 + 6 * ROWSH + 2 * 64;
-__host__ __device__ constexpr int lds_bytes(int S0) { return off_const(S0) + CONST_FLOATS * 4; }
+constexpr int CONST_FLOATS = 2 * HIDH + 2 * 128 + 6 * 128 + 2 * 64;
+__host__ __device__ constexpr int lds_bytes(int S0, int RT) { return off_const(S0, RT) + CONST_FLOATS * 4; }
 
 #ifdef CMBPO_STAMPS
 #define H3_STAMP(k)                                                         \
@@ -222,17 +233,29 @@ __device__ __forceinline__ void epi_stage(Epi4 &s, const f32x16 &d, int q, float
     if (PIN) asm volatile("" : "+v"(s.z[0]), "+v"(s.z[1]), "+v"(s.z[2]), "+v"(s.z[3]));
   } else if constexpr (K == 8) {
     s.q1[0] = s.q1[1] = 0u;
+    // (hipcc pads no hazard behind an asm statement: where the pieces feed an MFMA straight from the registers -- the
+    // tail, PIN == false -- the wait states between a VALU write and an MFMA's operand read stand inside the string)
     asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(s.q1[0]) : "v"(s.z[0]), "v"(tn));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(s.q1[0]) : "v"(s.z[1]), "v"(tn));
     asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(s.q1[1]) : "v"(s.z[2]), "v"(tn));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(s.q1[1]) : "v"(s.z[3]), "v"(tn));
+    if constexpr (PIN) {
+      asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(s.q1[0]) : "v"(s.z[1]), "v"(tn));
+      asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(s.q1[1]) : "v"(s.z[3]), "v"(tn));
+    } else {
+      asm("v_fma_mixhi_f16 %0, %1, %2, 0\n\ts_nop 1" : "+v"(s.q1[0]) : "v"(s.z[1]), "v"(tn));
+      asm("v_fma_mixhi_f16 %0, %1, %2, 0\n\ts_nop 1" : "+v"(s.q1[1]) : "v"(s.z[3]), "v"(tn));
+    }
     if (PIN) asm volatile("" : "+v"(s.q1[0]), "+v"(s.q1[1]));
   } else if constexpr (K == 9) {
     s.q2[0] = s.q2[1] = 0u;
     asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(s.q2[0]) : "v"(s.z[0]), "v"(tn), "v"(s.q1[0]));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(s.q2[0]) : "v"(s.z[1]), "v"(tn), "v"(s.q1[0]));
     asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(s.q2[1]) : "v"(s.z[2]), "v"(tn), "v"(s.q1[1]));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(s.q2[1]) : "v"(s.z[3]), "v"(tn), "v"(s.q1[1]));
+    if constexpr (PIN) {
+      asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(s.q2[0]) : "v"(s.z[1]), "v"(tn), "v"(s.q1[0]));
+      asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(s.q2[1]) : "v"(s.z[3]), "v"(tn), "v"(s.q1[1]));
+    } else {
+      asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\ts_nop 1" : "+v"(s.q2[0]) : "v"(s.z[1]), "v"(tn), "v"(s.q1[0]));
+      asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\ts_nop 1" : "+v"(s.q2[1]) : "v"(s.z[3]), "v"(tn), "v"(s.q1[1]));
+    }
     if (PIN) asm volatile("" : "+v"(s.q2[0]), "+v"(s.q2[1]));
   }
 }
@@ -244,8 +267,12 @@ __device__ __forceinline__ void epi_all(Epi4 &s, const f32x16 &d, int q, float i
   epi_stage<9, PIN>(s, d, q, inv, bv, tn);
 }
 
-template <int S0, int OTP>   // k-slabs of the input layer (in_pad <= 16 S0); output n-tiles, 2 or 4 (2 out_dim <= 32 OTP)
+// S0: k-slabs of the input layer (in_pad <= 16 S0); OTP: output n-tiles, 2 or 4 (2 out_dim <= 32 OTP); RT: 32-row tiles per item
+template <int S0, int OTP, int RT>
 __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
+  using G = Geo<RT>;
+  constexpr int ROWSH = G::ROWS, NTC = G::NTC, CK = G::CK, NCH = G::NCH, SLC = G::SLC, CSTR = G::CSTR, TPR = G::TPR,
+                KPT = G::KPT, DA = G::DA, CBUF_BYTES = G::CBUF_BYTES;
   constexpr int XSTR = 16 * S0 + 8;
   constexpr int NPASS = OTP / 2;         // output tiles are taken two at a time
   constexpr int NUNIT = RT * NPASS;      // (row tile, pass) units of the tail
@@ -256,15 +283,15 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
   char *smem = reinterpret_cast<char *>(smem4);
   _Float16 *cbuf = reinterpret_cast<_Float16 *>(smem);                               // [2][2][128][CSTR]
   _Float16 *ximg = reinterpret_cast<_Float16 *>(smem + 2 * CBUF_BYTES);              // [2][128][XSTR]
-  f16x8 *w0buf = reinterpret_cast<f16x8 *>(smem + 2 * CBUF_BYTES + ximg_bytes(S0));   // [2][W0P][64]
+  f16x8 *w0buf = reinterpret_cast<f16x8 *>(smem + 2 * CBUF_BYTES + ximg_bytes(S0, RT));   // [2][W0P][64] (RT == 4 only)
   f32x4 *pbuf = reinterpret_cast<f32x4 *>(smem);                                     // [2][8 waves][2 tiles][4][64] x 16 B
   float *stg = reinterpret_cast<float *>(smem + 2 * PBUF_BYTES);                     // [2][32][SWS]
-  float *cst = reinterpret_cast<float *>(smem + off_const(S0));
+  float *cst = reinterpret_cast<float *>(smem + off_const(S0, RT));
   float *bias0 = cst, *bias1 = cst + HIDH, *hc_a = cst + 2 * HIDH, *hc_c = hc_a + 128;
   int *rowidx = reinterpret_cast<int *>(hc_c + 128);
-  float *r_inv0 = reinterpret_cast<float *>(rowidx) + ROWSH, *r_t1 = r_inv0 + ROWSH, *r_inv1 = r_t1 + ROWSH,
-        *r_t2 = r_inv1 + ROWSH, *r_inv2 = r_t2 + ROWSH;
-  float *in_mu_l = r_inv2 + ROWSH, *in_sig_l = in_mu_l + 64;
+  float *r_inv0 = reinterpret_cast<float *>(rowidx) + 128, *r_t1 = r_inv0 + 128, *r_inv1 = r_t1 + 128, *r_t2 = r_inv1 + 128,
+        *r_inv2 = r_t2 + 128;
+  float *in_mu_l = r_inv2 + 128, *in_sig_l = in_mu_l + 64;
 
   const int n_rows = p.n_rows_dev ? *p.n_rows_dev : p.n_rows;
   const int out = p.out_dim;
@@ -278,11 +305,11 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
   // ---- prefetch registers: the NEXT item's raw input rows, biases and output bias travel behind the current item's tail.
   // Every load is unconditional (clamped addresses, the selection happens on the values): a load inside a per-element
   // branch makes hipcc wait for it there, one memory round trip per element.
-  float xpre[16];
+  float xpre[KPT];
   float bpre[2], b2pre = 0.0f;
   int rr_pre = -1;
   auto fetch_row = [&](int it, int tid) {
-    const int xb = tid >> 2;
+    const int xb = tid / TPR;
     const int e2 = it / p.tiles;
     const int rr = (it - e2 * p.tiles) * ROWSH + xb;
     const bool ok = it < p.n_items && rr < n_rows;
@@ -291,13 +318,13 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
     rr_pre = ok ? v : -1;
   };
   auto fetch_x = [&](int tid) {
-    const int xc = tid & 3;
+    const int xc = tid % TPR;
     const int rr = rr_pre >= 0 ? rr_pre : 0;
     const float *orow = p.obs + (size_t)rr * p.obs_dim;
     const float *arow = p.act_dim > 0 ? p.act + (size_t)rr * p.act_dim - p.obs_dim : orow;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int k = 16 * xc + u;
+    for (int u = 0; u < KPT; ++u) {
+      const int k = KPT * xc + u;
       const float *q = (k < p.obs_dim) ? orow + k : ((k < p.in_dim) ? arow + k : orow);
       xpre[u] = *q;
     }
@@ -325,7 +352,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
     asm volatile("v_mov_b32 %0, %0" : "+v"(tid));
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int xb = tid >> 2, xc = tid & 3;      // stage: row of the item, 16-wide k part
+    const int xb = tid / TPR, xc = tid % TPR;   // stage: row of the item, KPT-wide k part
     const int e = item / p.tiles;
     const int row0 = (item - e * p.tiles) * ROWSH;
     if (row0 >= n_rows) {    // (uniform) nothing alive in this tile; keep the prefetch chain going
@@ -338,12 +365,14 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
     // ---- stage: constants, per-row scales, the split input image, the first two W0 chunks --------------------------
     const f16x8 *w0e = a.w0 + (size_t)e * a.w0_stride;
     {
-      constexpr int W0R = (2 * W0P + kWavesH - 1) / kWavesH;
+      constexpr int W0R = G::W0_LDS ? (2 * W0P + kWavesH - 1) / kWavesH : 1;
       f16x8 w0r[W0R];
+      if constexpr (G::W0_LDS) {
 #pragma unroll
-      for (int u = 0; u < W0R; ++u) {
-        const int j = wave + kWavesH * u;
-        w0r[u] = w0e[(size_t)(j < 2 * W0P ? j : 0) * 64 + lane];
+        for (int u = 0; u < W0R; ++u) {
+          const int j = wave + kWavesH * u;
+          w0r[u] = w0e[(size_t)(j < 2 * W0P ? j : 0) * 64 + lane];
+        }
       }
       bias0[tid] = bpre[0];
       bias1[tid] = bpre[1];
@@ -356,18 +385,18 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
         hc_a[tid] = A;
         hc_c[tid] = A * b2pre + Bc;
       }
-      float xs[16];
+      float xs[KPT];
       float m = 0.0f;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int k = 16 * xc + u;
+      for (int u = 0; u < KPT; ++u) {
+        const int k = KPT * xc + u;
         float x = (xpre[u] - in_mu_l[k & 63]) / in_sig_l[k & 63];
         x = (k < p.in_dim && rr_pre >= 0) ? x : 0.0f;
         xs[u] = x;
         m = fmaxf(m, fabsf(x));
       }
-      m = fmaxf(m, __shfl_xor(m, 1, 64));
-      m = fmaxf(m, __shfl_xor(m, 2, 64));
+#pragma unroll
+      for (int o = 1; o < TPR; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
       const float t0 = pow2_lift(m);
       if (xc == 0) {
         const float bound1 = (st[1] * m + st[2]) * 1.001f, t1 = pow2_lift(bound1);
@@ -379,22 +408,32 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
         r_t2[xb] = t2;
         r_inv2[xb] = 1.0f / (st[8] * t2);
       }
-      if (xc < S0) {
-        f16x8 q1[2], q2[2];
+      if (KPT * xc < 16 * S0) {
+        _Float16 q1[KPT], q2[KPT];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          _Float16 c1, c2;
-          split_h(xs[u] * t0, c1, c2);
-          q1[u >> 3][u & 7] = c1; q2[u >> 3][u & 7] = c2;
+        for (int u = 0; u < KPT; ++u) split_h(xs[u] * t0, q1[u], q2[u]);
+        _Float16 *d1 = ximg + (size_t)xb * XSTR + KPT * xc, *d2 = d1 + (size_t)ROWSH * XSTR;
+        if constexpr (KPT >= 8) {
+#pragma unroll
+          for (int v = 0; v < KPT / 8; ++v) {
+            f16x8 w1, w2;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { w1[u] = q1[8 * v + u]; w2[u] = q2[8 * v + u]; }
+            reinterpret_cast<f16x8 *>(d1)[v] = w1; reinterpret_cast<f16x8 *>(d2)[v] = w2;
+          }
+        } else {
+          f16x4 w1, w2;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { w1[u] = q1[u]; w2[u] = q2[u]; }
+          *reinterpret_cast<f16x4 *>(d1) = w1; *reinterpret_cast<f16x4 *>(d2) = w2;
         }
-        f16x8 *d1 = reinterpret_cast<f16x8 *>(ximg + (size_t)xb * XSTR + 16 * xc);
-        f16x8 *d2 = reinterpret_cast<f16x8 *>(ximg + (size_t)(ROWSH + xb) * XSTR + 16 * xc);
-        d1[0] = q1[0]; d1[1] = q1[1]; d2[0] = q2[0]; d2[1] = q2[1];
       }
+      if constexpr (G::W0_LDS) {
 #pragma unroll
-      for (int u = 0; u < W0R; ++u) {
-        const int j = wave + kWavesH * u;
-        if (j < 2 * W0P) w0buf[(size_t)j * 64 + lane] = w0r[u];     // chunks 0, 1
+        for (int u = 0; u < W0R; ++u) {
+          const int j = wave + kWavesH * u;
+          if (j < 2 * W0P) w0buf[(size_t)j * 64 + lane] = w0r[u];     // chunks 0, 1
+        }
       }
     }
     fetch_row(item + gridDim.x, tid);     // the next item's row index: lands during the layers
@@ -409,7 +448,10 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
     // layer-0 operands of one 16-deep slab: W0 fragments of the chunk (LDS copy) and this wave's rows of the x image
     struct L0Ops { f16x8 a1, a2, b1, b2; };
     auto l0_read = [&](L0Ops &o, int cc, int s) {
-      const f16x8 *wa = w0buf + ((size_t)(cc & 1) * W0P + (size_t)l0_tn * S0 * 2 + 2 * s) * 64 + lane;
+      // W0 fragments: the chunk's LDS copy when several waves share an n-tile (RT == 4), straight from L2 otherwise (the
+      // step after the last chunk computes a chunk nobody reads: any valid address will do)
+      const f16x8 *wa = G::W0_LDS ? w0buf + ((size_t)(cc & 1) * W0P + (size_t)l0_tn * S0 * 2 + 2 * s) * 64 + lane
+                                  : w0e + (((size_t)(cc < NCH ? cc : NCH - 1) * NTC + l0_tn) * S0 * 2 + 2 * s) * 64 + lane;
       o.a1 = wa[0]; o.a2 = wa[64];
       o.b1 = *reinterpret_cast<const f16x8 *>(xb0 + 16 * s);
       o.b2 = *reinterpret_cast<const f16x8 *>(xb0 + (size_t)ROWSH * XSTR + 16 * s);
@@ -431,7 +473,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][bt][i] = 0.0f;
     const f16x8 *w1a = a.w1 + (size_t)e * a.w1_stride + (size_t)(2 * wave) * 32 * 128 + lane;   // [tile][slab 32][piece][lane]
-    f16x8 A[2][2][2];      // [ping-pong][n-tile][piece]
+    f16x8 A[DA][2][2];     // ring over the layer-1 slabs: [slab % DA][n-tile][piece], DA - 1 slabs of lookahead
     f16x8 Bt[3][2];        // rolling window over the (slab, row tile) sequence: current, +1, +2 (two LDS reads in flight)
     auto load_a = [&](f16x8 (&x)[2][2], int s) {
 #pragma unroll
@@ -445,7 +487,8 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
       x[0] = *reinterpret_cast<const f16x8 *>(q);
       x[1] = *reinterpret_cast<const f16x8 *>(q + (size_t)ROWSH * CSTR);
     };
-    load_a(A[0], 0);
+#pragma unroll
+    for (int s = 0; s < DA - 1; ++s) load_a(A[s], s);
     {   // chunk 0 of h1: nothing to overlap it with yet
       f32x16 d;
 #pragma unroll
@@ -467,11 +510,11 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
     __syncthreads();
     H3_STAMP(2);
 
-    // One step = the 96 layer-1 MFMAs of chunk c (8 groups of 12: slab x row-tile pair) with the production of chunk
-    // c + 1 dealt out between them: a wave issues in order, so what stands between two MFMAs runs in the shadow of the
-    // first.  Groups 0 .. S0-1 carry the layer-0 MFMAs of one input slab each (operands read one group ahead), groups
-    // 4 .. 7 one quarter of the swish / lift / split epilogue each, one piece behind every MFMA.  The last step produces a
-    // chunk nobody reads (branch-free; its reads stay inside the workgroup's LDS).
+    // One step = the 96 layer-1 MFMAs of chunk c -- 16 (slab, row tile) positions of 6, in 8 groups of 12 -- with the
+    // production of chunk c + 1 dealt out between them: a wave issues in order, so what stands between two MFMAs runs in the
+    // shadow of the first.  Groups 0 .. S0-1 carry the layer-0 MFMAs of one input slab each (operands read one group
+    // ahead), groups 4 .. 7 one quarter of the swish / lift / split epilogue each, one piece behind every MFMA.  The last
+    // step produces a chunk nobody reads (branch-free; its reads stay inside the workgroup's LDS / the member's weights).
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
       f16x8 wst;
@@ -485,61 +528,65 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
       Epi4 es;
       f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
       read_bt(Bt[0], img, 0, 0);
-      read_bt(Bt[1], img, 1, 0);
+      read_bt(Bt[1], img, 1 % RT, 1 / RT);
       l0_read(l0, c + 1, 0);
 #pragma unroll
-      for (int sl = 0; sl < SLC; ++sl) {
-        const int s = c * SLC + sl;
-        f16x8(&Ac)[2][2] = A[sl & 1];
-        f16x8(&An)[2][2] = A[(sl & 1) ^ 1];
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const int slot = 2 * sl + g;
-          if (g == 0) load_a(An, s + 1 < 32 ? s + 1 : s);
-          if (slot >= 4) bv = l0_bias(c + 1, slot - 4);
+      for (int slot = 0; slot < 8; ++slot) {
+        if (slot >= 4) bv = l0_bias(c + 1, slot - 4);
+        if constexpr (G::W0_LDS) {
           // W0 fragments of chunk c + 2 pass through four registers, one 1-KB piece at a time
           if (slot == 4) wst = w0e[((size_t)cw * W0P + wave) * 64 + lane];
           if (slot == 5 && W0P > kWavesH) {
             if (stage_w0) w0buf[((size_t)(c & 1) * W0P + wave) * 64 + lane] = wst;
             wst = w0e[((size_t)cw * W0P + (wave + kWavesH < W0P ? wave + kWavesH : wave)) * 64 + lane];
           }
-          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-          for (int i = 0; i < 12; ++i) {
-            const int b = i / 6, t = (i / 3) % 2, term = i % 3;
-            const int pos = 4 * sl + 2 * g + b;                     // position in the (slab, row tile) sequence
-            if (i % 6 == 0 && pos + 2 < 4 * SLC) read_bt(Bt[(pos + 2) % 3], img, (pos + 2) & 3, (pos + 2) >> 2);
-            f32x16 &ac = acc[t][2 * g + b];
-            const f16x8 &b1 = Bt[pos % 3][0], &b2 = Bt[pos % 3][1];
-            if (term == 0) ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[t][1], b1, ac, 0, 0, 0);
-            else if (term == 1) ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[t][0], b2, ac, 0, 0, 0);
-            else ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[t][0], b1, ac, 0, 0, 0);
-            if (slot < S0 && i == 5) {          // layer-0 MFMAs of input slab `slot`, then the next slab's operands
-              mm3(d, l0.a1, l0.a2, l0.b1, l0.b2);
-              if (slot + 1 < S0) l0_read(l0, c + 1, slot + 1);
+        for (int i = 0; i < 12; ++i) {
+          const int pos = 2 * slot + i / 6;                       // position in the (slab, row tile) sequence
+          const int sl = pos / RT, bt = pos % RT;
+          const int t = (i / 3) % 2, term = i % 3;
+          if (i % 6 == 0) {
+            if (bt == 0) {                                         // a new slab: request the one DA - 1 ahead
+              const int sn = c * SLC + sl + DA - 1;
+              load_a(A[(sl + DA - 1) % DA], sn < 32 ? sn : 31);
             }
-            if (slot >= 4) {
-              const int q = slot - 4;
-              if (i == 0) epi_stage<0, true>(es, d, q, inv0_l, bv, t1_l);
-              if (i == 1) epi_stage<1, true>(es, d, q, inv0_l, bv, t1_l);
-              if (i == 2) epi_stage<2, true>(es, d, q, inv0_l, bv, t1_l);
-              if (i == 3) epi_stage<3, true>(es, d, q, inv0_l, bv, t1_l);
-              if (i == 4) epi_stage<4, true>(es, d, q, inv0_l, bv, t1_l);
-              if (i == 5) epi_stage<5, true>(es, d, q, inv0_l, bv, t1_l);
-              if (i == 6) epi_stage<6, true>(es, d, q, inv0_l, bv, t1_l);
-              if (i == 7) epi_stage<7, true>(es, d, q, inv0_l, bv, t1_l);
-              if (i == 8) epi_stage<8, true>(es, d, q, inv0_l, bv, t1_l);
-              if (i == 9) epi_stage<9, true>(es, d, q, inv0_l, bv, t1_l);
-              if (i == 10) l0_store(es, c + 1, q);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            if (pos + 2 < 16) read_bt(Bt[(pos + 2) % 3], img, (pos + 2) % RT, (pos + 2) / RT);
+            if (i == 0) __builtin_amdgcn_sched_barrier(0);
           }
+          f16x8(&Ac)[2][2] = A[sl % DA];
+          f32x16 &ac = acc[t][bt];
+          const f16x8 &b1 = Bt[pos % 3][0], &b2 = Bt[pos % 3][1];
+          if (term == 0) ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[t][1], b1, ac, 0, 0, 0);
+          else if (term == 1) ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[t][0], b2, ac, 0, 0, 0);
+          else ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[t][0], b1, ac, 0, 0, 0);
+          if (slot < S0 && i == 5) {          // layer-0 MFMAs of input slab `slot`, then the next slab's operands
+            mm3(d, l0.a1, l0.a2, l0.b1, l0.b2);
+            if (slot + 1 < S0) l0_read(l0, c + 1, slot + 1);
+          }
+          if (slot >= 4) {
+            const int q = slot - 4;
+            if (i == 0) epi_stage<0, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 1) epi_stage<1, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 2) epi_stage<2, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 3) epi_stage<3, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 4) epi_stage<4, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 5) epi_stage<5, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 6) epi_stage<6, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 7) epi_stage<7, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 8) epi_stage<8, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 9) epi_stage<9, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 10) l0_store(es, c + 1, q);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       H3_STAMP(4);
-      if (stage_w0) {
-        const int j = W0P > kWavesH ? wave + kWavesH : wave;
-        if (j < W0P) w0buf[((size_t)(c & 1) * W0P + j) * 64 + lane] = wst;
+      if constexpr (G::W0_LDS) {
+        if (stage_w0) {
+          const int j = W0P > kWavesH ? wave + kWavesH : wave;
+          if (j < W0P) w0buf[((size_t)(c & 1) * W0P + j) * 64 + lane] = wst;
+        }
       }
       __syncthreads();
       H3_STAMP(5);
@@ -713,6 +760,13 @@ static int ensure_h3(cmbpo_mlp *m, hipStream_t s) {
   return CMBPO_OK;
 }
 
+static int g_h3_rt = getenv("CMBPO_ENS_H3_RT") ? atoi(getenv("CMBPO_ENS_H3_RT")) : 0;   // 0: by row count; 1 / 2 / 4 forces it
+extern "C" int cmbpo_set_ens_f16_row_tiles(int rt) {
+  CMBPO_REQUIRE(rt == 0 || rt == 1 || rt == 2 || rt == 4, "cmbpo_set_ens_f16_row_tiles: 0 (by row count), 1, 2 or 4");
+  g_h3_rt = rt;
+  return CMBPO_OK;
+}
+
 bool cmbpo_internal_h3_eligible(const cmbpo_mlp *m) {
   return m->head == CMBPO_HEAD_PROB && m->hidden == 512 && m->act == CMBPO_ACT_SWISH && m->o_tiles <= 4 && m->in_pad <= 64 &&
          2 * m->out_dim == m->o_width;
@@ -738,24 +792,41 @@ int cmbpo_internal_launch_h3(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
   }
-  const int tiles = cmbpo_ceil_div(a.n_rows, ROWSH);
+  // rows per item: 128 when that still gives every CU an item, else 64, else 32 (an item's latency is the step's when the
+  // launch is a single round of items)
+  const int E = m->ensemble;
+  int RT = g_h3_rt;
+  if (RT == 0) {
+    // fewest rounds of items x an item's time (measured alone on a CU, AntSafe shapes: 21 / 30 / 51 us at 32 / 64 / 128 rows)
+    const int t_us[3] = {21, 30, 51}, rts[3] = {1, 2, 4};
+    long best = -1;
+    for (int i = 0; i < 3; ++i) {
+      const long cost = (long)cmbpo_ceil_div(cmbpo_ceil_div(a.n_rows, 32 * rts[i]) * E, n_cu) * t_us[i];
+      if (best < 0 || cost <= best) { best = cost; RT = rts[i]; }
+    }
+  }
+  const int tiles = cmbpo_ceil_div(a.n_rows, 32 * RT);
   k.m.tiles = tiles;
-  k.m.n_items = tiles * m->ensemble;
+  k.m.n_items = tiles * E;
   const int S0 = m->h3_s0, OTP = m->h3_otp;
-  const size_t lds = (size_t)lds_bytes(S0);
+  const size_t lds = (size_t)lds_bytes(S0, RT);
   CMBPO_REQUIRE(lds <= 160 * 1024, "ens_h3: LDS budget exceeded (%zu B)", lds);
   const int grid = k.m.n_items < n_cu ? k.m.n_items : n_cu;
-  static size_t attr_done[5][5] = {};
-#define CMBPO_H3_CASE(S0_, OTP_)                                                                                       \
-  if (S0 == S0_ && OTP == OTP_) {                                                                                      \
-    if (!attr_done[S0_][OTP_]) {                                                                                       \
-      CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ens_h3_kernel<S0_, OTP_>),                    \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
-      attr_done[S0_][OTP_] = 1;                                                                                        \
+  static bool attr_done[5][5][5] = {};
+#define CMBPO_H3_CASE(S0_, OTP_, RT_)                                                                                  \
+  if (S0 == S0_ && OTP == OTP_ && RT == RT_) {                                                                         \
+    if (!attr_done[S0_][OTP_][RT_]) {                                                                                  \
+      CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ens_h3_kernel<S0_, OTP_, RT_>),               \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(S0_, RT_)));      \
+      attr_done[S0_][OTP_][RT_] = true;                                                                                \
     }                                                                                                                  \
-    hipLaunchKernelGGL((ens_h3_kernel<S0_, OTP_>), dim3(grid), dim3(kThreadsH), lds, s, k);                           \
+    hipLaunchKernelGGL((ens_h3_kernel<S0_, OTP_, RT_>), dim3(grid), dim3(kThreadsH), lds, s, k);                      \
   }
-  CMBPO_H3_CASE(2, 2) CMBPO_H3_CASE(3, 2) CMBPO_H3_CASE(4, 2) CMBPO_H3_CASE(2, 4) CMBPO_H3_CASE(3, 4) CMBPO_H3_CASE(4, 4)
+#define CMBPO_H3_CASES(RT_)                                                                                            \
+  CMBPO_H3_CASE(2, 2, RT_) CMBPO_H3_CASE(3, 2, RT_) CMBPO_H3_CASE(4, 2, RT_)                                           \
+  CMBPO_H3_CASE(2, 4, RT_) CMBPO_H3_CASE(3, 4, RT_) CMBPO_H3_CASE(4, 4, RT_)
+  CMBPO_H3_CASES(4) CMBPO_H3_CASES(2) CMBPO_H3_CASES(1)
+#undef CMBPO_H3_CASES
 #undef CMBPO_H3_CASE
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;

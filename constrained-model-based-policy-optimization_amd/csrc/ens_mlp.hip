@@ -706,9 +706,9 @@ int launch_one(MlpKernelArgs &a, int tiles, int chunks, size_t lds, hipStream_t 
 int g_block_rows = 32;  // 32 (2 workgroups / CU) or 64 (1 workgroup / CU)
 // matrix path of the 512-wide PROB forward: 0 fp32 MFMAs, 1 ens_split.hip (six bf16 terms), 2 ens_h3.hip (three f16 terms)
 int g_split_path = getenv("CMBPO_ENS_SPLIT") ? atoi(getenv("CMBPO_ENS_SPLIT")) : CMBPO_ENS_SPLIT_F16;
-// below ~1.5 k rows the f16 kernel's 128-row items leave most CUs idle and the bf16 kernel's 32-row items win (measured,
-// AntSafe shapes: 45 us against 53 at 1000 rows, 60 against 57 at 2000, 107 against 55 at 3000)
-int g_h3_min_rows = getenv("CMBPO_ENS_H3_MIN_ROWS") ? atoi(getenv("CMBPO_ENS_H3_MIN_ROWS")) : 1536;
+// rows below which the 512-wide forward falls back to the bf16 kernel: none since the f16 kernel has 32- and 64-row items
+// (22 us against the bf16 kernel's 43 at 1000 rows, AntSafe shapes); the knob stays for experiments
+int g_h3_min_rows = getenv("CMBPO_ENS_H3_MIN_ROWS") ? atoi(getenv("CMBPO_ENS_H3_MIN_ROWS")) : 0;
 int g_stagger = 10;     // x s_sleep(127) (~8k cycles each) for the second dispatch batch
 int g_lds_pad = 0;      // diagnostic: extra dynamic LDS bytes (forces one workgroup per CU)
 

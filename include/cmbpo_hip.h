@@ -84,6 +84,9 @@ int cmbpo_get_ens_matrix_path(void);
 /* Tuning knob: calls of the 512-wide probabilistic forward with fewer rows than this use CMBPO_ENS_SPLIT_BF16 even when
  * CMBPO_ENS_SPLIT_F16 is selected (its 128-row items leave CUs idle at small rollout batches); 0 = never. */
 int cmbpo_set_ens_f16_min_rows(int rows);
+/* Tuning knob: 32-row tiles per item of the CMBPO_ENS_SPLIT_F16 kernel: 4 (128-row items, the throughput shape), 2 or 1
+ * (the same kernel for rollout batches too small to give every CU a 128-row item); 0 (default) chooses by row count. */
+int cmbpo_set_ens_f16_row_tiles(int rt);
 
 /* ------------------------------------------------------------------------ *
  * Ensemble MLP handle: a 3-layer (in -> H -> H -> O) ensemble of E members.

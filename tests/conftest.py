@@ -29,4 +29,4 @@ def ens_path(hip_lib, request):
     hip_lib.cmbpo_set_ens_f16_min_rows(0)          # the f16 path at every size, also below its default threshold
     yield request.param
     hip_lib.cmbpo_set_ens_matrix_path(before)
-    hip_lib.cmbpo_set_ens_f16_min_rows(1536)
+    hip_lib.cmbpo_set_ens_f16_min_rows(0)

@@ -53,6 +53,30 @@ def test_ens_forward_matches_oracle(hip_lib, ens_path, task, n):
     np.testing.assert_allclose(var, rvar, rtol=2e-3, atol=1e-7)
 
 
+@pytest.mark.parametrize("rt", [1, 2, 4])
+@pytest.mark.parametrize("task", ["AntSafe-v2", "HalfCheetahSafe-v2", "HumanoidSafe-v2"])
+@pytest.mark.parametrize("n", [1, 33, 130, 1000])
+def test_ens_forward_f16_item_shapes(hip_lib, rt, task, n):
+    """The f16 matrix path at every item shape (32 / 64 / 128 rows per item), whatever the row count would choose."""
+    _cuda()
+    rng = np.random.default_rng(zlib.crc32(f"{task}/{n}/{rt}".encode()))
+    m, ws, bs, sc_in, sc_out, obs_dim, act_dim = _dyn_model(rng, task)
+    x = rng.standard_normal((n, obs_dim + act_dim)).astype(np.float32)
+    before = hip_lib.cmbpo_get_ens_matrix_path()
+    try:
+        assert hip_lib.cmbpo_set_ens_matrix_path(2) == 0 and hip_lib.cmbpo_set_ens_f16_min_rows(0) == 0
+        assert hip_lib.cmbpo_set_ens_f16_row_tiles(rt) == 0
+        mean, var = m.predict_ensemble(x)
+    finally:
+        hip_lib.cmbpo_set_ens_f16_row_tiles(0)
+        hip_lib.cmbpo_set_ens_f16_min_rows(0)
+        hip_lib.cmbpo_set_ens_matrix_path(before)
+    rmean, rvar = refcpu.ens_forward(x, ws, bs, sc_in, sc_out)
+    np.testing.assert_allclose(mean, rmean, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(var, rvar, rtol=2e-3, atol=1e-7)
+    assert hip_lib.cmbpo_set_ens_f16_row_tiles(3) < 0
+
+
 def test_ens_forward_no_scalers_hidden128(hip_lib):
     _cuda()
     from cmbpo_amd import synthetic
@@ -279,4 +303,4 @@ def test_ens_matrix_paths_agree_and_follow_weight_updates(hip_lib):
         assert hip_lib.cmbpo_set_ens_matrix_path(7) < 0
     finally:
         hip_lib.cmbpo_set_ens_matrix_path(before)
-        hip_lib.cmbpo_set_ens_f16_min_rows(1536)
+        hip_lib.cmbpo_set_ens_f16_min_rows(0)

@@ -27,8 +27,9 @@ for B in (128, 256, 512, 1000, 2000, 3000, 4000, 6000, 8000, 10000, 16000, 25000
     mean = torch.empty(E, B, obs_dim + 1, device="cuda")
     var = torch.empty_like(mean)
     out = []
-    for path in (1, 2):
+    for path, rt in ((1, 0), (2, 4), (2, 2), (2, 1)):
         lib.cmbpo_set_ens_matrix_path(path)
+        lib.cmbpo_set_ens_f16_row_tiles(rt)
         for _ in range(5):
             m.predict_ensemble(obs, act=act, out=(mean, var))
         torch.cuda.synchronize()
@@ -40,4 +41,4 @@ for B in (128, 256, 512, 1000, 2000, 3000, 4000, 6000, 8000, 10000, 16000, 25000
         e.record()
         torch.cuda.synchronize()
         out.append(s.elapsed_time(e) / iters * 1e3)
-    print(f"B={B:6d}  bf16x6 {out[0]:8.1f} us   f16x3 {out[1]:8.1f} us   ratio {out[0] / out[1]:.2f}", flush=True)
+    print(f"B={B:6d}  bf16x6 {out[0]:8.1f} us   f16x3 128-row {out[1]:8.1f}  64-row {out[2]:8.1f}  32-row {out[3]:8.1f} us", flush=True)

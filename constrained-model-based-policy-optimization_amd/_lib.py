@@ -45,6 +45,8 @@ SIGNATURES = {
     "cmbpo_mlp_load": (_i, [_p] * 13),
     "cmbpo_ens_forward": (_i, [_p, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p]),
     "cmbpo_ens_predict_mean": (_i, [_p, _p, _i, _p, _p, _i, _p, _p]),
+    "cmbpo_critic_pair_supported": (_i, [_p, _p]),
+    "cmbpo_critic_pair_predict": (_i, [_p, _p, _p, _i, _p, _p, _i, _p, _p, _p]),
     "cmbpo_policy_forward": (_i, [_p, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
     "cmbpo_fakeenv_post": (_i, [_i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i,
                                 _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -1,0 +1,275 @@
+// Both critics of a rollout step in ONE launch (CPOPolicy.get_v / get_vc, policies/cpo_policy.py:825-835 -> PE.predict,
+// models/pens/pe.py:338-343,648-669: the mean over ALL members of a 3-layer swish ensemble with one output), with every
+// float32 product as three f16 MFMAs (f16_split.h; arithmetic and scales exactly as in ens_h3.hip).
+//
+// A 128-wide member is too small to share among waves without paying a barrier and an LDS round trip per layer -- as two
+// launches of the general kernel the critics were 2 x 19 us of a 120 us step at 1000 branches, the largest item of it --
+// but on the f16 matrix cores a whole member is 120 MFMAs: ONE wave carries one member of one critic for a 32-row tile
+// from the input to the output without leaving its registers.  The input fragment is split in registers, layer 0's
+// accumulator tiles ARE layer 1's B operand (an accumulator tile's rows are the next product's k index; the W1 image is
+// packed in the matching k order), the single output column is a VALU dot product over the h2 registers.  A workgroup is
+// the 2 x E waves of a tile (both critics read the same observation rows); the members' values meet in LDS and are
+// averaged in member order.  No cross-workgroup traffic, no barrier before the final one.
+#include "common.h"
+#include "ens_mlp_internal.h"
+#include "f16_split.h"
+
+namespace {
+
+constexpr int HC = 128;          // hidden units
+constexpr int NT = HC / 32;      // n-tiles
+constexpr int S1 = HC / 16;      // k-slabs of layer 1
+
+struct CfNet {
+  const f16x8 *w0, *w1;          // images [member][n-tile][slab][piece][lane]
+  size_t w0_stride, w1_stride;   // per member, 16-B units
+  const float *b0, *b1, *w2, *b2;   // [E][128], [E][128], packed W2 ([E] x wp2_stride float4), [E][32]
+  size_t w2_stride;              // floats per member of the packed W2
+  const float *stats;            // [E][NSTAT]
+  const float *in_mu, *in_sig, *out_mu, *out_sig;   // or NULL
+  float *out;                    // [branch slot]
+};
+
+struct CfArgs {
+  CfNet net[2];
+  const float *obs;
+  int obs_dim, ensemble;
+  const int32_t *row_idx, *n_rows_dev;
+  int n_rows;
+};
+
+template <int S0>   // k-slabs of the input layer (obs_dim <= 16 S0)
+__global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
+  constexpr int KP = 16 * S0;
+  extern __shared__ float sm[];
+  float *xraw = sm;                         // [32][KP + 1] raw observation rows of the tile
+  float *part = xraw + 32 * (KP + 1);       // [2 E][32] member values
+  __shared__ int rows[32];
+  __shared__ float s_mu[2][KP], s_sig[2][KP];   // the critics' input scalers (identity where there is none)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int E = a.ensemble;
+  const int n_rows = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
+  const int row0 = blockIdx.x * 32;
+  if (row0 >= n_rows) return;
+  const int ni = wave / E, e = wave - ni * E;     // this wave's critic and member
+  const CfNet &N = a.net[ni];
+  // first weight fragments of layer 0: requested before anything else
+  const f16x8 *w0 = N.w0 + (size_t)e * N.w0_stride + lane;      // + ((tile * S0 + s) * 2 + piece) * 64
+  const f16x8 *w1 = N.w1 + (size_t)e * N.w1_stride + lane;      // + ((tile * S1 + s) * 2 + piece) * 64
+  f16x8 A[2][NT][2];
+  auto load_w = [&](f16x8 (&x)[NT][2], const f16x8 *w, int slabs, int s) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const f16x8 *q = w + ((size_t)(t * slabs + s) * 2) * 64;
+      x[t][0] = q[0]; x[t][1] = q[64];
+    }
+  };
+  load_w(A[0], w0, S0, 0);
+  if (tid < 32) {
+    const int rr = row0 + tid;
+    int v = rr < n_rows ? rr : 0;
+    if (a.row_idx) v = a.row_idx[v];
+    rows[tid] = rr < n_rows ? v : -1;
+  }
+  if (tid < 2 * KP) {
+    const int n2 = tid / KP, k = tid - n2 * KP;
+    const CfNet &M = a.net[n2];
+    const int kc = k < a.obs_dim ? k : 0;
+    s_mu[n2][k] = (M.in_mu && k < a.obs_dim) ? M.in_mu[kc] : 0.0f;
+    s_sig[n2][k] = (M.in_mu && k < a.obs_dim) ? M.in_sig[kc] : 1.0f;
+  }
+  __syncthreads();
+  for (int i = tid; i < 32 * KP; i += blockDim.x) {      // unconditional loads (clamped), the selection is on the values
+    const int b = i / KP, k = i - b * KP;
+    const int rr = rows[b];
+    const float x = a.obs[(size_t)(rr >= 0 ? rr : 0) * a.obs_dim + (k < a.obs_dim ? k : 0)];
+    xraw[b * (KP + 1) + k] = (rr >= 0 && k < a.obs_dim) ? x : 0.0f;
+  }
+  __syncthreads();
+  const float *st = N.stats + (size_t)e * NSTAT;
+
+  // ---- input fragment: this critic's scaler, the row's lift, the split -- in registers ---------------------------------
+  float xs[S0][8];
+  float m0 = 0.0f;
+#pragma unroll
+  for (int s = 0; s < S0; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * s + 8 * hh + j;
+      float x = (xraw[r * (KP + 1) + k] - s_mu[ni][k]) / s_sig[ni][k];   // TensorStandardScaler.transform, utils.py:156
+      if (k >= a.obs_dim) x = 0.0f;
+      xs[s][j] = x;
+      m0 = fmaxf(m0, fabsf(x));
+    }
+  m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));
+  const float t0 = pow2_lift(m0);
+  const float bound1 = (st[1] * m0 + st[2]) * 1.001f, t1 = pow2_lift(bound1);
+  const float inv0 = 1.0f / (st[0] * t0), inv1 = 1.0f / (st[4] * t1);
+
+  f32x16 acc[NT];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+  };
+  zero_acc();
+  // ---- layer 0 -------------------------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int s = 0; s < S0; ++s) {
+    if (s + 1 < S0) load_w(A[(s + 1) & 1], w0, S0, s + 1);
+    else load_w(A[(s + 1) & 1], w1, S1, 0);
+    f16x8 b1, b2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      _Float16 c1, c2;
+      split_h(xs[s][j] * t0, c1, c2);
+      b1[j] = c1; b2[j] = c2;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) mm3(acc[t], A[s & 1][t][0], A[s & 1][t][1], b1, b2);
+  }
+  // ---- h1 = swish(. + b0), lifted and split: accumulator registers 8 half .. + 7 of tile t are slab 2 t + half of layer 1
+  f16x8 bf[S1][2];
+  {
+    const float *b0 = N.b0 + (size_t)e * HC;
+    u32x4 bu[S1][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(b0 + 32 * t + 8 * q + 4 * hh);
+        Epi4 es;
+        epi_all<false>(es, acc[t], q, inv0, bv, t1);
+        const int S = 2 * t + (q >> 1), o = 2 * (q & 1);
+        bu[S][0][o] = es.q1[0]; bu[S][0][o + 1] = es.q1[1];
+        bu[S][1][o] = es.q2[0]; bu[S][1][o + 1] = es.q2[1];
+      }
+#pragma unroll
+    for (int S = 0; S < S1; ++S) { bf[S][0] = __builtin_bit_cast(f16x8, bu[S][0]); bf[S][1] = __builtin_bit_cast(f16x8, bu[S][1]); }
+  }
+  zero_acc();
+  // ---- layer 1 (its first fragments arrived behind the epilogue) -----------------------------------------------------------
+  constexpr int P0 = S0 & 1;      // ping-pong slot the first layer-1 fragments were loaded into
+#pragma unroll
+  for (int s = 0; s < S1; ++s) {
+    if (s + 1 < S1) load_w(A[(P0 + s + 1) & 1], w1, S1, s + 1);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) mm3(acc[t], A[(P0 + s) & 1][t][0], A[(P0 + s) & 1][t][1], bf[s][0], bf[s][1]);
+  }
+  // ---- h2 = swish(. + b1); output = h2 . W2[:, 0] + b2; output scaler ----------------------------------------------------
+  float dot = 0.0f;
+  {
+    const float *b1 = N.b1 + (size_t)e * HC;
+    const float *w2 = N.w2 + (size_t)e * N.w2_stride;     // packed [k-group][lane (n, h)][4]: (k, n = 0) at ((k >> 3) * 64 + ((k >> 2) & 1) * 32) * 4 + (k & 3)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k0 = 32 * t + 8 * q + 4 * hh;
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(b1 + k0);
+        const f32x4 wv = *reinterpret_cast<const f32x4 *>(w2 + ((size_t)(k0 >> 3) * 64 + ((k0 >> 2) & 1) * 32) * 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dot = __builtin_fmaf(swishf(__builtin_fmaf(acc[t][4 * q + s], inv1, bv[s])), wv[s], dot);
+      }
+  }
+  dot += __shfl_xor(dot, 32, 64);
+  const float o_sig = N.out_mu ? N.out_sig[0] : 1.0f, o_mu = N.out_mu ? N.out_mu[0] : 0.0f;
+  const float val = o_sig * (dot + N.b2[(size_t)e * 32]) + o_mu;       // inverse_transform, models/pens/utils.py:167
+  if (hh == 0) part[wave * 32 + r] = val;
+  __syncthreads();
+  if (tid < 64) {                   // mean over ALL members (pe.py:343), added in member order
+    const int n2 = tid >> 5, b = tid & 31;
+    float sum = 0.0f;
+    for (int m = 0; m < E; ++m) sum += part[(n2 * E + m) * 32 + b];
+    const int rr = rows[b];
+    if (rr >= 0) a.net[n2].out[rr] = sum / (float)E;
+  }
+}
+
+// (re)builds the two f16 images and the statistics of a 128-wide single-output ensemble when its packs changed
+int ensure_cf16(cmbpo_mlp *m, hipStream_t s) {
+  const int E = m->ensemble;
+  const int S0 = m->h3_s0;
+  if (m->d_h3 == nullptr) {
+    m->h3_stride[0] = (size_t)NT * S0 * 2 * 64;
+    m->h3_stride[1] = (size_t)NT * S1 * 2 * 64;
+    m->h3_stride[2] = 0;
+    m->h3_off[0] = 0;
+    m->h3_off[1] = m->h3_stride[0] * E;
+    m->h3_stats_off = m->h3_off[1] + m->h3_stride[1] * E;
+    const size_t bytes = m->h3_stats_off * 16 + (size_t)E * NSTAT * sizeof(float);
+    if (hipMalloc(&m->d_h3, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      m->d_h3 = nullptr;
+      cmbpo_set_error("critic_f16: hipMalloc of the f16 weight images failed");
+      return CMBPO_ENOMEM;
+    }
+    m->h3_version = ~0ul;
+  }
+  if (m->h3_version == m->pack_version) return CMBPO_OK;
+  float *stats = reinterpret_cast<float *>(reinterpret_cast<char *>(m->d_h3) + m->h3_stats_off * 16);
+  cmbpo_internal_f16_stats(m, stats, s);
+  f16x8 *base = reinterpret_cast<f16x8 *>(m->d_h3);
+  cmbpo_internal_f16_pack(m, 0, base + m->h3_off[0], m->h3_stride[0], NT, S0, 0, stats, s);
+  cmbpo_internal_f16_pack(m, 1, base + m->h3_off[1], m->h3_stride[1], NT, S1, 1, stats, s);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  m->h3_version = m->pack_version;
+  return CMBPO_OK;
+}
+
+bool pair_eligible(const cmbpo_mlp *m) {
+  return m->head == CMBPO_HEAD_DETMEAN && m->hidden == HC && m->act == CMBPO_ACT_SWISH && m->o_width == 1 && m->in_pad <= 64 &&
+         m->ensemble >= 1 && m->ensemble <= 4 && m->loaded;     // 2 E waves of up to 256 registers
+}
+
+}  // namespace
+
+extern "C" int cmbpo_critic_pair_supported(const cmbpo_mlp_t *v, const cmbpo_mlp_t *vc) {
+  return v && vc && pair_eligible(v) && pair_eligible(vc) && v->in_dim == vc->in_dim && v->ensemble == vc->ensemble ? 1 : 0;
+}
+
+extern "C" int cmbpo_critic_pair_predict(cmbpo_mlp_t *v, cmbpo_mlp_t *vc, const float *d_obs, int obs_dim, const int32_t *d_row_idx,
+                                         const int32_t *d_n_rows, int n_rows, float *d_v, float *d_vc, void *stream) {
+  CMBPO_REQUIRE(v && vc && d_obs && d_v && d_vc, "cmbpo_critic_pair_predict: NULL argument");
+  CMBPO_REQUIRE(cmbpo_critic_pair_supported(v, vc), "cmbpo_critic_pair_predict: needs two loaded 128-wide swish ensembles of equal "
+                                                    "size with one output (HEAD_DETMEAN)");
+  CMBPO_REQUIRE(obs_dim == v->in_dim, "cmbpo_critic_pair_predict: obs_dim %d, the critics take %d", obs_dim, v->in_dim);
+  CMBPO_REQUIRE(n_rows >= 0, "cmbpo_critic_pair_predict: n_rows %d", n_rows);
+  if (n_rows == 0) return CMBPO_OK;
+  hipStream_t s = (hipStream_t)stream;
+  CfArgs a{};
+  cmbpo_mlp *ms[2] = {v, vc};
+  float *outs[2] = {d_v, d_vc};
+  const int s0 = (v->in_pad + 15) / 16;
+  for (int i = 0; i < 2; ++i) {
+    cmbpo_mlp *m = ms[i];
+    if (m->h3_s0 == 0) m->h3_s0 = s0 < 2 ? 2 : s0;
+    if (int rc = ensure_cf16(m, s)) return rc;
+    const float *blob = m->d_blob;
+    CfNet &n = a.net[i];
+    const f16x8 *base = reinterpret_cast<const f16x8 *>(m->d_h3);
+    n.w0 = base + m->h3_off[0]; n.w1 = base + m->h3_off[1];
+    n.w0_stride = m->h3_stride[0]; n.w1_stride = m->h3_stride[1];
+    n.b0 = blob + m->off_b0; n.b1 = blob + m->off_b1; n.b2 = blob + m->off_b2;
+    n.w2 = blob + m->off_wp2; n.w2_stride = (size_t)m->o_tiles * (HC / 8) * 256;
+    n.stats = reinterpret_cast<const float *>(reinterpret_cast<const char *>(m->d_h3) + m->h3_stats_off * 16);
+    n.in_mu = m->has_in_scaler ? blob + m->off_in_mu : nullptr;
+    n.in_sig = m->has_in_scaler ? blob + m->off_in_var : nullptr;
+    n.out_mu = m->has_out_scaler ? blob + m->off_out_mu : nullptr;
+    n.out_sig = m->has_out_scaler ? blob + m->off_out_var : nullptr;
+    n.out = outs[i];
+  }
+  a.obs = d_obs; a.obs_dim = obs_dim; a.ensemble = v->ensemble;
+  a.row_idx = d_row_idx; a.n_rows_dev = d_n_rows; a.n_rows = n_rows;
+  const int S0 = ms[0]->h3_s0;
+  const int threads = 64 * 2 * v->ensemble;
+  const size_t lds = ((size_t)32 * (16 * S0 + 1) + (size_t)2 * v->ensemble * 32) * sizeof(float);
+  const int grid = cmbpo_ceil_div(n_rows, 32);
+  if (S0 == 2) hipLaunchKernelGGL(critic_pair_kernel<2>, dim3(grid), dim3(threads), lds, s, a);
+  else if (S0 == 3) hipLaunchKernelGGL(critic_pair_kernel<3>, dim3(grid), dim3(threads), lds, s, a);
+  else hipLaunchKernelGGL(critic_pair_kernel<4>, dim3(grid), dim3(threads), lds, s, a);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}

@@ -32,19 +32,15 @@
 // pass through an LDS staging tile so that rows are stored as contiguous runs.
 #include "common.h"
 #include "ens_mlp_internal.h"
+#include "f16_split.h"
 
 #include <stdlib.h>
 
 namespace {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
 constexpr int kThreadsH = 512;
 constexpr int kWavesH = 8;
 constexpr int HIDH = 512;
-constexpr int NSTAT = 12;             // floats per member in the stats block: {s, L1, B, -} x 3 layers
 
 // Geometry of an item of RT 32-row tiles (4: the throughput shape; 2 / 1: the same kernel for rollout batches too small
 // to give every CU a 128-row item -- an item's latency is the step's there).  Whatever RT, a chunk of h1 is 8 (n-tile,
@@ -95,38 +91,12 @@ __host__ __device__ constexpr int lds_bytes(int S0, int RT) { return off_const(S
 #define H3_STAMP(k) do { } while (0)
 #endif
 
-__device__ __forceinline__ float swishf(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-
-// 2^k with v 2^k in [2^13, 2^14); 1 for zero, subnormal and non-finite v
-__host__ __device__ __forceinline__ float pow2_lift(float v) {
-  union { float f; unsigned u; } c;
-  c.f = v;
-  const int ex = (int)((c.u >> 23) & 255u);
-  if (ex == 0 || ex == 255) return 1.0f;
-  int k = 13 - (ex - 127);
-  k = k < -100 ? -100 : (k > 100 ? 100 : k);
-  c.u = (unsigned)(k + 127) << 23;
-  return c.f;
-}
-
-__device__ __forceinline__ void split_h(float a, _Float16 &p1, _Float16 &p2) {
-  p1 = (_Float16)a;
-  p2 = (_Float16)(a - (float)p1);   // exact difference
-}
-
-// three-term product, smallest terms first
-__device__ __forceinline__ void mm3(f32x16 &acc, const f16x8 &a1, const f16x8 &a2, const f16x8 &b1, const f16x8 &b2) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
-}
-
 // ---- per-member statistics of the fp32 packs: max |W|, largest column 1-norm, max |b| -----------------------------------
 // pack layout [n-tile][k-group][lane (r, h)][4]: W[k = 8 g + 4 h + s][n = 32 tile + r].  grid (E, 3), 512 threads.
 __global__ void h3_stats_kernel(const float *blob, size_t off0, size_t off1, size_t off2, size_t offb0, size_t offb1, size_t offb2,
-                                int kg0, int o_tiles, float *stats) {
+                                int kg0, int o_tiles, int hidden, float *stats) {
   const int e = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
-  const int tiles = l == 2 ? o_tiles : HIDH / 32, kg = l == 0 ? kg0 : HIDH / 8;
+  const int tiles = l == 2 ? o_tiles : hidden / 32, kg = l == 0 ? kg0 : hidden / 8;
   const size_t woff = l == 0 ? off0 : (l == 1 ? off1 : off2), boff = l == 0 ? offb0 : (l == 1 ? offb1 : offb2);
   const float *w = blob + woff + (size_t)e * tiles * kg * 256;
   const float *b = blob + boff + (size_t)e * tiles * 32;
@@ -194,78 +164,6 @@ struct H3Args {
   size_t w0_stride, w1_stride, w2_stride;   // per member, in 16-B units
   const float *stats;                        // [E][NSTAT]
 };
-
-// ---- the swish / lift / split epilogue of four accumulator values, cut into twelve pieces of at most ~20 issue cycles
-// so that one piece can stand behind each MFMA of a 12-MFMA group (a wave issues in order: what stands between two MFMAs
-// runs in the shadow of the first).  The split uses the mixed-precision FMAs: p1 = f16(x t) and p2 = f16(x t - p1) are
-// one v_fma_mix{lo,hi}_f16 each -- the product is exact inside the FMA, so p1 + p2 = x t (1 + d), |d| <= 2^-24, with a
-// single rounding per piece -- and lo / hi write the two halves of a dword, so the pieces come out packed.
-// PIN: an empty volatile asm after each piece keeps the compiler from sinking it into a later piece.
-struct Epi4 {
-  float z[4], e[4];
-  unsigned q1[2], q2[2];   // p1 / p2 of the four values, packed f16x2
-};
-template <int K, bool PIN>
-__device__ __forceinline__ void epi_stage(Epi4 &s, const f32x16 &d, int q, float inv, const f32x4 &bv, float tn) {
-  if constexpr (K == 0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s.z[i] = __builtin_fmaf(d[4 * q + i], inv, bv[i]);
-    if (PIN) asm volatile("" : "+v"(s.z[0]), "+v"(s.z[1]), "+v"(s.z[2]), "+v"(s.z[3]));
-  } else if constexpr (K == 1) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s.e[i] = s.z[i] * -1.4426950408889634f;
-    if (PIN) asm volatile("" : "+v"(s.e[0]), "+v"(s.e[1]), "+v"(s.e[2]), "+v"(s.e[3]));
-  } else if constexpr (K == 2 || K == 3) {
-    constexpr int o = 2 * (K - 2);
-    s.e[o] = __builtin_amdgcn_exp2f(s.e[o]); s.e[o + 1] = __builtin_amdgcn_exp2f(s.e[o + 1]);
-    if (PIN) asm volatile("" : "+v"(s.e[o]), "+v"(s.e[o + 1]));
-  } else if constexpr (K == 4) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s.e[i] = 1.0f + s.e[i];
-    if (PIN) asm volatile("" : "+v"(s.e[0]), "+v"(s.e[1]), "+v"(s.e[2]), "+v"(s.e[3]));
-  } else if constexpr (K == 5 || K == 6) {
-    constexpr int o = 2 * (K - 5);
-    s.e[o] = __builtin_amdgcn_rcpf(s.e[o]); s.e[o + 1] = __builtin_amdgcn_rcpf(s.e[o + 1]);
-    if (PIN) asm volatile("" : "+v"(s.e[o]), "+v"(s.e[o + 1]));
-  } else if constexpr (K == 7) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s.z[i] = s.z[i] * s.e[i];
-    if (PIN) asm volatile("" : "+v"(s.z[0]), "+v"(s.z[1]), "+v"(s.z[2]), "+v"(s.z[3]));
-  } else if constexpr (K == 8) {
-    s.q1[0] = s.q1[1] = 0u;
-    // (hipcc pads no hazard behind an asm statement: where the pieces feed an MFMA straight from the registers -- the
-    // tail, PIN == false -- the wait states between a VALU write and an MFMA's operand read stand inside the string)
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(s.q1[0]) : "v"(s.z[0]), "v"(tn));
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(s.q1[1]) : "v"(s.z[2]), "v"(tn));
-    if constexpr (PIN) {
-      asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(s.q1[0]) : "v"(s.z[1]), "v"(tn));
-      asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(s.q1[1]) : "v"(s.z[3]), "v"(tn));
-    } else {
-      asm("v_fma_mixhi_f16 %0, %1, %2, 0\n\ts_nop 1" : "+v"(s.q1[0]) : "v"(s.z[1]), "v"(tn));
-      asm("v_fma_mixhi_f16 %0, %1, %2, 0\n\ts_nop 1" : "+v"(s.q1[1]) : "v"(s.z[3]), "v"(tn));
-    }
-    if (PIN) asm volatile("" : "+v"(s.q1[0]), "+v"(s.q1[1]));
-  } else if constexpr (K == 9) {
-    s.q2[0] = s.q2[1] = 0u;
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(s.q2[0]) : "v"(s.z[0]), "v"(tn), "v"(s.q1[0]));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(s.q2[1]) : "v"(s.z[2]), "v"(tn), "v"(s.q1[1]));
-    if constexpr (PIN) {
-      asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(s.q2[0]) : "v"(s.z[1]), "v"(tn), "v"(s.q1[0]));
-      asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(s.q2[1]) : "v"(s.z[3]), "v"(tn), "v"(s.q1[1]));
-    } else {
-      asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\ts_nop 1" : "+v"(s.q2[0]) : "v"(s.z[1]), "v"(tn), "v"(s.q1[0]));
-      asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\ts_nop 1" : "+v"(s.q2[1]) : "v"(s.z[3]), "v"(tn), "v"(s.q1[1]));
-    }
-    if (PIN) asm volatile("" : "+v"(s.q2[0]), "+v"(s.q2[1]));
-  }
-}
-template <bool PIN>
-__device__ __forceinline__ void epi_all(Epi4 &s, const f32x16 &d, int q, float inv, const f32x4 &bv, float tn) {
-  epi_stage<0, PIN>(s, d, q, inv, bv, tn); epi_stage<1, PIN>(s, d, q, inv, bv, tn); epi_stage<2, PIN>(s, d, q, inv, bv, tn);
-  epi_stage<3, PIN>(s, d, q, inv, bv, tn); epi_stage<4, PIN>(s, d, q, inv, bv, tn); epi_stage<5, PIN>(s, d, q, inv, bv, tn);
-  epi_stage<6, PIN>(s, d, q, inv, bv, tn); epi_stage<7, PIN>(s, d, q, inv, bv, tn); epi_stage<8, PIN>(s, d, q, inv, bv, tn);
-  epi_stage<9, PIN>(s, d, q, inv, bv, tn);
-}
 
 // S0: k-slabs of the input layer (in_pad <= 16 S0); OTP: output n-tiles, 2 or 4 (2 out_dim <= 32 OTP); RT: 32-row tiles per item
 template <int S0, int OTP, int RT>
@@ -744,7 +642,7 @@ static int ensure_h3(cmbpo_mlp *m, hipStream_t s) {
   if (m->h3_version == m->pack_version) return CMBPO_OK;
   float *stats = reinterpret_cast<float *>(reinterpret_cast<char *>(m->d_h3) + m->h3_stats_off * 16);
   hipLaunchKernelGGL(h3_stats_kernel, dim3(E, 3), dim3(kThreadsH), 0, s, m->d_blob, m->off_wp0, m->off_wp1, m->off_wp2,
-                     m->off_b0, m->off_b1, m->off_b2, m->in_pad / 8, m->o_tiles, stats);
+                     m->off_b0, m->off_b1, m->off_b2, m->in_pad / 8, m->o_tiles, H, stats);
   const size_t src_off[3] = {m->off_wp0, m->off_wp1, m->off_wp2};
   const int kg[3] = {m->in_pad / 8, H / 8, H / 8};
   const int src_tiles[3] = {H / 32, H / 32, m->o_tiles};
@@ -758,6 +656,24 @@ static int ensure_h3(cmbpo_mlp *m, hipStream_t s) {
   CMBPO_HIP_CHECK(hipGetLastError());
   m->h3_version = m->pack_version;
   return CMBPO_OK;
+}
+
+// shared with critic_f16.hip
+void cmbpo_internal_f16_stats(const cmbpo_mlp *m, float *stats, hipStream_t s) {
+  hipLaunchKernelGGL(h3_stats_kernel, dim3(m->ensemble, 3), dim3(kThreadsH), 0, s, m->d_blob, m->off_wp0, m->off_wp1, m->off_wp2,
+                     m->off_b0, m->off_b1, m->off_b2, m->in_pad / 8, m->o_tiles, m->hidden, stats);
+}
+void cmbpo_internal_f16_pack(const cmbpo_mlp *m, int layer, void *dst, size_t dst_stride, int n_tiles, int slabs, int perm,
+                             const float *stats, hipStream_t s) {
+  const int H = m->hidden;
+  const size_t src_off[3] = {m->off_wp0, m->off_wp1, m->off_wp2};
+  const int kg[3] = {m->in_pad / 8, H / 8, H / 8};
+  const int src_tiles[3] = {H / 32, H / 32, m->o_tiles};
+  const size_t src_stride = (size_t)src_tiles[layer] * kg[layer] * 256;
+  const long total = (long)n_tiles * slabs * 64 * m->ensemble;
+  hipLaunchKernelGGL(h3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, m->d_blob + src_off[layer], src_stride,
+                     kg[layer], src_tiles[layer], reinterpret_cast<f16x8 *>(dst), dst_stride, n_tiles, slabs, m->ensemble, stats, layer,
+                     perm);
 }
 
 static int g_h3_rt = getenv("CMBPO_ENS_H3_RT") ? atoi(getenv("CMBPO_ENS_H3_RT")) : 0;   // 0: by row count; 1 / 2 / 4 forces it

@@ -1,6 +1,6 @@
 // One imagined step of every alive branch as ONE call (samplers/model_sampler.py:239-375): policy forward, ensemble
 // forward, FakeEnv post-processing, finish decisions, pre-store finishes, store, both critics at the next observations,
-// post-store finishes -- the nine launches sequences the host mirror otherwise makes through nine separate calls.  At the
+// post-store finishes -- the launch sequence the host mirror otherwise makes through nine separate calls.  At the
 // rollout batch sizes of the shipped configs (1e3 - 1e4 branches) a step is bound by host latency, not by the kernels.
 // Every buffer is a field of the rollout struct; nothing here adds arithmetic.
 #include "common.h"
@@ -26,7 +26,12 @@ extern "C" int cmbpo_rollout_step(const cmbpo_rollout_t *r, int n_alive, cmbpo_m
   if ((rc = cmbpo_rollout_decide(r, stream))) return rc;
   if ((rc = cmbpo_rollout_finish(r, 0, stream))) return rc;
   if ((rc = cmbpo_rollout_store(r, stream))) return rc;
-  if ((rc = cmbpo_ens_predict_mean(v, r->next_obs, r->obs_dim, r->alive_idx, nullptr, n_alive, w(r->v_n), stream))) return rc;
-  if ((rc = cmbpo_ens_predict_mean(vc, r->next_obs, r->obs_dim, r->alive_idx, nullptr, n_alive, w(r->vc_n), stream))) return rc;
+  if (cmbpo_critic_pair_supported(v, vc)) {      // both critics in one launch (csrc/critic_f16.hip)
+    if ((rc = cmbpo_critic_pair_predict(v, vc, r->next_obs, r->obs_dim, r->alive_idx, nullptr, n_alive, w(r->v_n), w(r->vc_n), stream)))
+      return rc;
+  } else {
+    if ((rc = cmbpo_ens_predict_mean(v, r->next_obs, r->obs_dim, r->alive_idx, nullptr, n_alive, w(r->v_n), stream))) return rc;
+    if ((rc = cmbpo_ens_predict_mean(vc, r->next_obs, r->obs_dim, r->alive_idx, nullptr, n_alive, w(r->vc_n), stream))) return rc;
+  }
   return cmbpo_rollout_finish(r, 1, stream);
 }

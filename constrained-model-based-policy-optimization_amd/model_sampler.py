@@ -123,6 +123,12 @@ class ModelSampler:
         t = self.pool.t
         idx = t["alive_idx"]
         lib, stream = _lib.lib(), _lib.current_stream()
+        v, vc = self.policy.v.mlp.handle, self.policy.vc.mlp.handle
+        if lib.cmbpo_critic_pair_supported(v, vc):       # both critics in one launch
+            _lib.check(lib.cmbpo_critic_pair_predict(v, vc, t[obs_key].data_ptr(), self.pool.obs_dim, idx.data_ptr(), None, n,
+                                                     t[v_key].data_ptr(), t[vc_key].data_ptr(), stream),
+                       "cmbpo_critic_pair_predict")
+            return
         for net, key in ((self.policy.v, v_key), (self.policy.vc, vc_key)):
             _lib.check(lib.cmbpo_ens_predict_mean(net.mlp.handle, t[obs_key].data_ptr(), self.pool.obs_dim,
                                                   idx.data_ptr(), None, n, t[key].data_ptr(), stream),

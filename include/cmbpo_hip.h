@@ -134,6 +134,15 @@ int cmbpo_ens_predict_mean(cmbpo_mlp_t *m, const float *d_obs, int obs_dim,
                            const int32_t *d_row_idx, const int32_t *d_n_rows,
                            int n_rows, float *d_out, void *stream);
 
+/* Both critics of a rollout step in one launch: CPOPolicy.get_v and get_vc (policies/cpo_policy.py:825-835) on the same
+ * observation rows -- two loaded HEAD_DETMEAN ensembles of 128 hidden units, swish, one output, equal input width and
+ * member count (<= 4).  Same function as two cmbpo_ens_predict_mean calls; float32 products run as three f16 MFMAs
+ * (csrc/critic_f16.hip), one wave per (critic, member).  d_v / d_vc are [branch slot]. */
+int cmbpo_critic_pair_supported(const cmbpo_mlp_t *v, const cmbpo_mlp_t *vc);
+int cmbpo_critic_pair_predict(cmbpo_mlp_t *v, cmbpo_mlp_t *vc, const float *d_obs, int obs_dim,
+                              const int32_t *d_row_idx, const int32_t *d_n_rows, int n_rows,
+                              float *d_v, float *d_vc, void *stream);
+
 /* mlp_gaussian_policy forward (network/ac_network.py:99-123) behind
  * CPOPolicy.get_action_outs (policies/cpo_policy.py:801-823): mu = MLP(obs),
  * pi = mu + eps*exp(log_std), logp_pi = gaussian_likelihood(pi, mu, log_std)

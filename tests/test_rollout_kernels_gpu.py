@@ -273,6 +273,48 @@ def test_fake_env_step_end_to_end(hip_lib):
     np.testing.assert_array_equal(info["cost"], refcpu.antsafe_c_fn(obs, act, nobs).astype(np.float32))
 
 
+@pytest.mark.parametrize("obs_dim", [20, 29, 47])
+@pytest.mark.parametrize("n", [1, 31, 33, 257, 5000])
+def test_critic_pair_matches_oracle(hip_lib, n, obs_dim):
+    """Both critics in one launch (three f16 MFMAs per float32 product, one wave per member) == PE.predict of each:
+    the oracle's mean over all members, and the general kernel's value, through a row index list."""
+    dev = _cuda()
+    from cmbpo_amd import _lib, synthetic
+    from cmbpo_amd.pens import PE
+    rng = np.random.default_rng(zlib.crc32(f"pair/{n}/{obs_dim}".encode()))
+    nets, refs = [], []
+    B = n + 7
+    obs = (rng.standard_normal((B, obs_dim)) * np.exp(rng.standard_normal((B, 1)))).astype(np.float32)   # rows of different scale
+    idx = np.sort(rng.choice(B, size=n, replace=False)).astype(np.int32)
+    for k in range(2):
+        ws, bs = synthetic.ensemble_weights(rng, 3, obs_dim, 128, 1, bias_scale=0.1)
+        sc_in, sc_out = synthetic.scaler(rng, obs_dim), synthetic.scaler(rng, 1)
+        m = PE(obs_dim, 1, hidden_dims=(128, 128), num_networks=3, num_elites=2, loss="MSE", use_scaler_in=True,
+               use_scaler_out=(k == 0), device="cuda:0")
+        m.set_weights(ws, bs, sc_in, sc_out if k == 0 else None)
+        nets.append(m)
+        refs.append(refcpu.ens_predict_mean(obs[idx], ws, bs, sc_in, sc_out if k == 0 else None)[:, 0])
+    lib = hip_lib
+    assert lib.cmbpo_critic_pair_supported(nets[0].mlp.handle, nets[1].mlp.handle) == 1
+    o = torch.from_numpy(obs).to(dev)
+    ix = torch.from_numpy(idx).to(dev)
+    out = [torch.full((B,), float("nan"), device=dev) for _ in range(2)]
+    _lib.check(lib.cmbpo_critic_pair_predict(nets[0].mlp.handle, nets[1].mlp.handle, o.data_ptr(), obs_dim, ix.data_ptr(), None, n,
+                                             out[0].data_ptr(), out[1].data_ptr(), _lib.current_stream()), "pair")
+    for k in range(2):
+        got = out[k].cpu().numpy()
+        np.testing.assert_allclose(got[idx], refs[k], rtol=1e-4, atol=1e-4)
+        assert np.isnan(got[np.setdiff1d(np.arange(B), idx)]).all()          # rows outside the list are never written
+        single = nets[k].predict(obs[idx])[:, 0]                                # the general kernel (fp32 MFMAs)
+        np.testing.assert_allclose(got[idx], single, rtol=2e-5, atol=2e-5)
+    # new weights are followed
+    ws2, bs2 = synthetic.ensemble_weights(rng, 3, obs_dim, 128, 1, bias_scale=0.1)
+    nets[1].set_weights(ws2, bs2, synthetic.scaler(rng, obs_dim), None)
+    _lib.check(lib.cmbpo_critic_pair_predict(nets[0].mlp.handle, nets[1].mlp.handle, o.data_ptr(), obs_dim, ix.data_ptr(), None, n,
+                                             out[0].data_ptr(), out[1].data_ptr(), _lib.current_stream()), "pair")
+    np.testing.assert_allclose(out[1].cpu().numpy()[idx], nets[1].predict(obs[idx])[:, 0], rtol=2e-5, atol=2e-5)
+
+
 def test_ens_matrix_paths_agree_and_follow_weight_updates(hip_lib):
     """The three matrix paths of the 512-wide forward differ by float32 rounding only (far inside the parity tolerance),
     and the split paths' bf16 / f16 weight images follow every change of the weights."""

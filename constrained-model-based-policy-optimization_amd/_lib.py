@@ -86,6 +86,10 @@ SIGNATURES.update({
     "cmbpo_rollout_count": (_i, [_rp, _p]),
     "cmbpo_rollout_finish": (_i, [_rp, _i, _p]),
     "cmbpo_rollout_store": (_i, [_rp, _p]),
+    "cmbpo_rollout_book_pre_max_rows": (_i, []),
+    "cmbpo_rollout_book_pre": (_i, [_rp, _i, _p]),
+    "cmbpo_rollout_book_post": (_i, [_rp, _i, _p]),
+    "cmbpo_rollout_read_scalars": (_i, [_rp, _p, _p]),
     "cmbpo_rollout_compact": (_i, [_rp, _p]),
     "cmbpo_rollout_step": (_i, [_rp, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
     "cmbpo_buffer_offsets": (_i, [_rp, _p, _p]),

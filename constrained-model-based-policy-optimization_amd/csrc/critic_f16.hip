@@ -57,7 +57,11 @@ __global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
   // first weight fragments of layer 0: requested before anything else
   const f16x8 *w0 = N.w0 + (size_t)e * N.w0_stride + lane;      // + ((tile * S0 + s) * 2 + piece) * 64
   const f16x8 *w1 = N.w1 + (size_t)e * N.w1_stride + lane;      // + ((tile * S1 + s) * 2 + piece) * 64
-  f16x8 A[2][NT][2];
+  // The wave streams its member's weights alone (80 KB from L2) and every slab is 12 MFMAs = 0.2 us of work against a load
+  // latency several times that: all of W0 and the first slabs of W1 are requested before the input is even staged, and
+  // layer 1 keeps a ring of RW slabs in flight.
+  constexpr int RW = S0 <= 2 ? 3 : 2;
+  f16x8 A0[S0][NT][2], R[3][NT][2];
   auto load_w = [&](f16x8 (&x)[NT][2], const f16x8 *w, int slabs, int s) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -65,7 +69,10 @@ __global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
       x[t][0] = q[0]; x[t][1] = q[64];
     }
   };
-  load_w(A[0], w0, S0, 0);
+#pragma unroll
+  for (int s = 0; s < S0; ++s) load_w(A0[s], w0, S0, s);
+#pragma unroll
+  for (int s = 0; s < RW; ++s) load_w(R[s], w1, S1, s);
   if (tid < 32) {
     const int rr = row0 + tid;
     int v = rr < n_rows ? rr : 0;
@@ -118,8 +125,6 @@ __global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
   // ---- layer 0 -------------------------------------------------------------------------------------------------------------
 #pragma unroll
   for (int s = 0; s < S0; ++s) {
-    if (s + 1 < S0) load_w(A[(s + 1) & 1], w0, S0, s + 1);
-    else load_w(A[(s + 1) & 1], w1, S1, 0);
     f16x8 b1, b2;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
       b1[j] = c1; b2[j] = c2;
     }
 #pragma unroll
-    for (int t = 0; t < NT; ++t) mm3(acc[t], A[s & 1][t][0], A[s & 1][t][1], b1, b2);
+    for (int t = 0; t < NT; ++t) mm3(acc[t], A0[s][t][0], A0[s][t][1], b1, b2);
   }
   // ---- h1 = swish(. + b0), lifted and split: accumulator registers 8 half .. + 7 of tile t are slab 2 t + half of layer 1
   f16x8 bf[S1][2];
@@ -150,13 +155,13 @@ __global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
     for (int S = 0; S < S1; ++S) { bf[S][0] = __builtin_bit_cast(f16x8, bu[S][0]); bf[S][1] = __builtin_bit_cast(f16x8, bu[S][1]); }
   }
   zero_acc();
-  // ---- layer 1 (its first fragments arrived behind the epilogue) -----------------------------------------------------------
-  constexpr int P0 = S0 & 1;      // ping-pong slot the first layer-1 fragments were loaded into
+  // ---- layer 1 (its first fragments arrived behind layer 0 and the epilogue) ------------------------------------------------
+  if constexpr (RW < 3) load_w(R[2], w1, S1, 2);      // (the third ring slot: free now that W0 is consumed)
 #pragma unroll
   for (int s = 0; s < S1; ++s) {
-    if (s + 1 < S1) load_w(A[(P0 + s + 1) & 1], w1, S1, s + 1);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) mm3(acc[t], A[(P0 + s) & 1][t][0], A[(P0 + s) & 1][t][1], bf[s][0], bf[s][1]);
+    for (int t = 0; t < NT; ++t) mm3(acc[t], R[s % 3][t][0], R[s % 3][t][1], bf[s][0], bf[s][1]);
+    if (s + 3 < S1) load_w(R[s % 3], w1, S1, s + 3);
   }
   // ---- h2 = swish(. + b1); output = h2 . W2[:, 0] + b2; output scaler ----------------------------------------------------
   float dot = 0.0f;

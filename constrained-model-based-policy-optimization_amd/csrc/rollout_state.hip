@@ -201,6 +201,40 @@ __global__ __launch_bounds__(kScanThreads) void decide_budget_kernel(const cmbpo
   if (tid == 0) r.iscal[CMBPO_I_N_FIN_PRE] = n_unc + (int)nf;
 }
 
+// reward + cost GAE of one finished path and its termination mark (modelbuffer.py:138-182; discount_cumsum =
+// lfilter([1], [1, -g*l]) on the reversed row with a float64 state, utilities/utils.py:184-188)
+__device__ __forceinline__ void gae_finish_path(const cmbpo_rollout_t &r, int b, float lv, float lcv, bool zero_boot) {
+  const int L = r.len[b];
+  const size_t B = (size_t)r.B;
+  const float g32 = (float)r.gamma, cg32 = (float)r.cost_gamma;
+  const double gl = r.gamma * r.lam, cgl = r.cost_gamma * r.cost_lam;
+  double y = 0.0, cy = 0.0;
+  float vnext = lv, cvnext = lcv;
+  for (int t = L - 1; t >= 0; --t) {
+    const size_t o = (size_t)t * B + b;
+    const float rw = r.rew_buf[o], v = r.val_buf[o], c = r.cost_buf[o], cv = r.cval_buf[o];
+    double delta;
+    if (zero_boot) {
+      // float64 arithmetic: rews/vals were promoted by the float64 zeros bootstrap
+      delta = __dsub_rn(__dadd_rn((double)rw, __dmul_rn(r.gamma, (double)vnext)), (double)v);
+    } else {
+      delta = (double)__fsub_rn(__fadd_rn(rw, __fmul_rn(g32, vnext)), v);
+    }
+    const float cdelta = __fsub_rn(__fadd_rn(c, __fmul_rn(cg32, cvnext)), cv);
+    // lfilter([1], [1, -g*l]) on the reversed row, float64 state: y = x + (g*l)*y_prev
+    y = __dadd_rn(delta, __dmul_rn(gl, y));
+    cy = __dadd_rn((double)cdelta, __dmul_rn(cgl, cy));
+    const float adv = (float)y, cadv = (float)cy;
+    r.adv_buf[o] = adv;
+    r.ret_buf[o] = __fadd_rn(adv, v);
+    r.cadv_buf[o] = cadv;
+    r.cret_buf[o] = __fadd_rn(cadv, cv);
+    vnext = v;
+    cvnext = cv;
+  }
+  r.alive[b] = 0;
+}
+
 // ---- finish: reward + cost GAE, then mark terminated (modelbuffer.py:138-182) -------------------
 __global__ __launch_bounds__(256) void finish_kernel(const cmbpo_rollout_t r, int mode) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -237,35 +271,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const cmbpo_rollout_t r, in
     lv = r.v_t[b];
     lcv = r.vc_t[b];
   }
-  const int L = r.len[b];
-  const size_t B = (size_t)r.B;
-  const float g32 = (float)r.gamma, cg32 = (float)r.cost_gamma;
-  const double gl = r.gamma * r.lam, cgl = r.cost_gamma * r.cost_lam;
-  double y = 0.0, cy = 0.0;
-  float vnext = lv, cvnext = lcv;
-  for (int t = L - 1; t >= 0; --t) {
-    const size_t o = (size_t)t * B + b;
-    const float rw = r.rew_buf[o], v = r.val_buf[o], c = r.cost_buf[o], cv = r.cval_buf[o];
-    double delta;
-    if (zero_boot) {
-      // float64 arithmetic: rews/vals were promoted by the float64 zeros bootstrap
-      delta = __dsub_rn(__dadd_rn((double)rw, __dmul_rn(r.gamma, (double)vnext)), (double)v);
-    } else {
-      delta = (double)__fsub_rn(__fadd_rn(rw, __fmul_rn(g32, vnext)), v);
-    }
-    const float cdelta = __fsub_rn(__fadd_rn(c, __fmul_rn(cg32, cvnext)), cv);
-    // lfilter([1], [1, -g*l]) on the reversed row, float64 state: y = x + (g*l)*y_prev
-    y = __dadd_rn(delta, __dmul_rn(gl, y));
-    cy = __dadd_rn((double)cdelta, __dmul_rn(cgl, cy));
-    const float adv = (float)y, cadv = (float)cy;
-    r.adv_buf[o] = adv;
-    r.ret_buf[o] = __fadd_rn(adv, v);
-    r.cadv_buf[o] = cadv;
-    r.cret_buf[o] = __fadd_rn(cadv, cv);
-    vnext = v;
-    cvnext = cv;
-  }
-  r.alive[b] = 0;
+  gae_finish_path(r, b, lv, lcv, zero_boot);
 }
 
 // ---- store: transition -> column ptr, sampler accumulators ---------------------------------------
@@ -374,6 +380,201 @@ __global__ __launch_bounds__(256) void store_stats_kernel(const cmbpo_rollout_t 
     r.dscal[CMBPO_D_TOTAL_DKL] += dkl_mean * cnt;
     r.dscal[CMBPO_D_MAX_DKL] = fmax(r.dscal[CMBPO_D_MAX_DKL], s[6]);
     r.dscal[CMBPO_D_MAX_PATH_RETURN] = fmax(r.dscal[CMBPO_D_MAX_PATH_RETURN], s[7]);
+  }
+}
+
+// ---- small rollout batches: decide -> finish(PRE) -> store -> statistics as ONE workgroup --------------------------------
+// At the shipped configurations' 1e3 - 1e4 branches each of the five kernels above is a few microseconds of work behind a
+// launch boundary (decide 2 x 5, finish 5, store 9 + 6 us of a 140 us step at 1000 branches).  Up to kBookMax alive rows
+// one 1024-thread workgroup walks them in a fixed order: same decisions, same per-branch arithmetic, the step's sums added
+// in a fixed tree.  (Single-rank path: the cross-shard budget exchange keeps the separate kernels.)
+constexpr int kBookMax = 4096;
+
+__global__ __launch_bounds__(kScanThreads) void book_pre_kernel(const cmbpo_rollout_t r) {
+  __shared__ int sm_i[17];
+  __shared__ double sm_d[16];
+  __shared__ int s_unc;
+  const int tid = threadIdx.x;
+  const int n = r.iscal[CMBPO_I_N_ALIVE];
+  // (1) uncertainty flags + this step's counters (decide_flags_kernel / head of decide_budget_kernel)
+  {
+    double c = 0.0, d = 0.0;
+    for (int i = tid; i < n; i += kScanThreads) {
+      const int b = r.alive_idx[i];
+      const bool u = too_uncertain(r, b);
+      r.fin_code[b] = u ? 1 : 0;
+      c += u ? 1.0 : 0.0;
+      d += (double)r.dkl_t[b];
+    }
+    c = block_sum(c, sm_d);
+    d = block_sum(d, sm_d);
+    if (tid == 0) {
+      s_unc = (int)c;
+      r.iscal[CMBPO_I_N_UNC] = (int)c;
+      r.dscal[CMBPO_D_DKL_SUM_T] = d;
+      r.iscal[CMBPO_I_N_STORED] = 0;
+      r.iscal[CMBPO_I_N_FIN_POST] = 0;
+      r.iscal[8] = n; r.iscal[9] = (int)c; r.iscal[10] = (int)r.dscal[CMBPO_D_TOTAL_SAMPLES]; r.iscal[11] = 0;
+      r.iscal[CMBPO_I_N_FIN_PRE] = (int)c;
+    }
+    __syncthreads();
+  }
+  const int n_unc = s_unc;
+  // (2) budget rule: the first `excess` surviving rows in index order are finished too (model_sampler.py:282-287)
+  if (r.max_samples != 0) {
+    const long long excess = (long long)r.dscal[CMBPO_D_TOTAL_SAMPLES] + n - n_unc - (long long)r.max_samples;
+    if (excess > 0) {
+      int carry = 0, nfin = 0;
+      for (int base = 0; base < n; base += kScanThreads) {
+        const int i = base + tid;
+        int b = -1, flag = 0;
+        if (i < n) {
+          b = r.alive_idx[i];
+          flag = r.fin_code[b] ? 0 : 1;
+        }
+        int total;
+        const int excl = block_excl_scan(flag, sm_i, &total);
+        if (flag && ((long long)carry + excl < excess)) {
+          r.fin_code[b] = 1;
+          nfin += 1;
+        }
+        carry += total;
+        if ((long long)carry >= excess) break;   // uniform: carry is a block-wide value
+      }
+      const double nf = block_sum((double)nfin, sm_d);
+      if (tid == 0) r.iscal[CMBPO_I_N_FIN_PRE] = n_unc + (int)nf;
+    }
+  }
+  // (every thread set the codes of its own rows only: rows i = tid, tid + 1024, ... in all three passes)
+  // (3) finish(PRE) + (4) the scalar half of the store
+  const size_t B = (size_t)r.B;
+  const int D = r.obs_dim;
+  double a_cnt = 0, a_cost = 0, a_rew = 0, a_v = 0, a_vc = 0, a_epv = 0, a_maxdkl = 0, a_maxret = 0;
+  for (int i = tid; i < n; i += kScanThreads) {
+    const int b = r.alive_idx[i];
+    const uint8_t code = r.fin_code[b];
+    if (code) {
+      gae_finish_path(r, b, code == 2 ? 0.0f : r.v_t[b], r.vc_t[b], code == 2);
+      continue;
+    }
+    const size_t col = (size_t)r.ptr * B + b;
+    const float rw = r.rew_t[b], c = r.cost_t[b], v = r.v_t[b], vc = r.vc_t[b];
+    const float epv = r.epv_t[b], dk = r.dkl_t[b];
+    r.rew_buf[col] = rw;
+    r.val_buf[col] = v;
+    r.cost_buf[col] = c;
+    r.cval_buf[col] = vc;
+    r.logp_buf[col] = r.logp_t[b];
+    r.len[b] = r.ptr + 1;
+    const double pr = r.path_ret[b] + (double)rw;
+    r.path_ret[b] = pr;
+    r.path_cost[b] += (double)c;
+    r.path_dyn_var[b] += (double)epv;
+    r.dkl_acc[b] += (double)dk;
+    a_cnt += 1.0; a_cost += c; a_rew += rw; a_v += v; a_vc += vc;
+    a_epv += (double)epv * D;
+    a_maxdkl = fmax(a_maxdkl, (double)dk);
+    a_maxret = fmax(a_maxret, pr);
+  }
+  // (the vector fields -- obs, act, mu, log_std: 53 floats per row at AntSafe shapes -- are copied by store_vec_kernel on
+  // many CUs: one workgroup moving them took 25 of this kernel's 34 us at 1000 rows)
+  // (5) the step's sums into the accumulators (store_stats_kernel)
+  const double s0 = block_sum(a_cnt, sm_d), s1 = block_sum(a_cost, sm_d), s2 = block_sum(a_rew, sm_d);
+  const double s3 = block_sum(a_v, sm_d), s4 = block_sum(a_vc, sm_d), s5 = block_sum(a_epv, sm_d);
+  const double s6 = block_max(a_maxdkl, sm_d), s7 = block_max(a_maxret, sm_d);
+  if (tid == 0 && s0 > 0.0) {
+    const double dkl_mean = r.dscal[CMBPO_D_DKL_SUM_T] / (double)n;  // np.mean over the rows stepped
+    r.iscal[CMBPO_I_N_STORED] += (int)s0;
+    r.iscal[CMBPO_I_SIZE] += (int)s0;
+    r.dscal[CMBPO_D_TOTAL_SAMPLES] += s0;
+    r.dscal[CMBPO_D_TOTAL_COST] += s1;
+    r.dscal[CMBPO_D_TOTAL_REW] += s2;
+    r.dscal[CMBPO_D_SUM_PATH_RET] += s2;
+    r.dscal[CMBPO_D_SUM_PATH_COST] += s1;
+    r.dscal[CMBPO_D_TOTAL_VS] += s3;
+    r.dscal[CMBPO_D_TOTAL_CVS] += s4;
+    r.dscal[CMBPO_D_TOTAL_DYN_EP_VAR] += s5;
+    r.dscal[CMBPO_D_TOTAL_DKL] += dkl_mean * s0;
+    r.dscal[CMBPO_D_MAX_DKL] = fmax(r.dscal[CMBPO_D_MAX_DKL], s6);
+    r.dscal[CMBPO_D_MAX_PATH_RETURN] = fmax(r.dscal[CMBPO_D_MAX_PATH_RETURN], s7);
+  }
+}
+
+// the vector half of the store for book_pre_kernel's decisions: 64-row tiles on as many workgroups
+__global__ __launch_bounds__(256) void store_vec_kernel(const cmbpo_rollout_t r) {
+  __shared__ int s_slot[kStoreRows];
+  const int n = r.iscal[CMBPO_I_N_ALIVE];
+  const int tid = threadIdx.x;
+  const int row0 = blockIdx.x * kStoreRows;
+  if (row0 >= n) return;
+  if (tid < kStoreRows) {
+    const int i = row0 + tid;
+    int b = -1;
+    if (i < n) {
+      b = r.alive_idx[i];
+      if (r.fin_code[b]) b = -1;
+    }
+    s_slot[tid] = b;
+  }
+  __syncthreads();
+  const size_t B = (size_t)r.B;
+  const int rows_here = min(kStoreRows, n - row0);
+  const float *vsrc[4] = {r.cur_obs, r.act_t, r.mu_t, r.ls_t};
+  float *vdst[4] = {r.obs_buf, r.act_buf, r.mu_buf, r.ls_buf};
+  const int vdim[4] = {r.obs_dim, r.act_dim, r.act_dim, r.act_dim};
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int dim = vdim[f];
+    const float inv = 1.0f / (float)dim;
+    for (int e = tid; e < rows_here * dim; e += 256) {
+      const int k = (int)(((float)e + 0.5f) * inv);   // exact for e < 2^16
+      const int d = e - k * dim;
+      const int b = s_slot[k];
+      if (b >= 0) vdst[f][((size_t)r.ptr * B + b) * dim + d] = vsrc[f][(size_t)b * dim + d];
+    }
+  }
+}
+
+// finish(POST) + compaction as one workgroup (small rollout batches): the horizon / environment-terminal finishes of
+// finish_kernel(mode 1), then the ordered alive list of the survivors into alive_idx_out.  The list is ALWAYS written (a
+// copy when nothing finished), so the host swaps alive_idx <-> alive_idx_out after every step without a second look.
+__global__ __launch_bounds__(kScanThreads) void book_post_kernel(const cmbpo_rollout_t r) {
+  __shared__ int sm_i[17];
+  __shared__ double sm_d[16];
+  const int tid = threadIdx.x;
+  const int n = r.iscal[CMBPO_I_N_ALIVE];
+  const bool horizon = (r.ptr + 1 >= r.max_path_length - 1);     // path_length after the store, model_sampler.py:352
+  int nfin = 0;
+  for (int i = tid; i < n; i += kScanThreads) {
+    const int b = r.alive_idx[i];
+    if (r.fin_code[b]) continue;              // finished before the store
+    if (horizon) {
+      gae_finish_path(r, b, r.v_n[b], r.vc_n[b], false);
+      ++nfin;
+    } else if (r.term_t[b]) {
+      gae_finish_path(r, b, 0.0f, r.vc_n[b], true);   // float64 zeros bootstrap; the cost value still bootstraps (:364)
+      ++nfin;
+    }
+  }
+  const double nf = block_sum((double)nfin, sm_d);
+  if (tid == 0) r.iscal[CMBPO_I_N_FIN_POST] = (int)nf;
+  __syncthreads();                              // (every thread marked its own rows only; the scan below re-reads them)
+  int carry = 0;
+  for (int base = 0; base < n; base += kScanThreads) {
+    const int i = base + tid;
+    int b = -1, flag = 0;
+    if (i < n) {
+      b = r.alive_idx[i];
+      flag = r.alive[b] ? 1 : 0;
+    }
+    int total;
+    const int excl = block_excl_scan(flag, sm_i, &total);
+    if (flag) r.alive_idx_out[carry + excl] = b;
+    carry += total;
+  }
+  if (tid == 0) {
+    r.iscal[CMBPO_I_N_ALIVE_OUT] = carry;
+    r.iscal[CMBPO_I_N_ALIVE] = carry;           // the caller swaps alive_idx <-> alive_idx_out
   }
 }
 
@@ -780,6 +981,48 @@ extern "C" int cmbpo_rollout_store(const cmbpo_rollout_t *r, void *stream) {
   hipLaunchKernelGGL(store_kernel, dim3(cmbpo_ceil_div(r->B, kStoreRows)), dim3(256), 0, (hipStream_t)stream, *r);
   hipLaunchKernelGGL(store_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *r);
   CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_rollout_book_pre_max_rows(void) { return kBookMax; }
+
+extern "C" int cmbpo_rollout_book_pre(const cmbpo_rollout_t *r, int n_alive, void *stream) {
+  if (int rc = check_rollout(r, "cmbpo_rollout_book_pre")) return rc;
+  CMBPO_REQUIRE(n_alive >= 0 && n_alive <= kBookMax, "cmbpo_rollout_book_pre: %d alive rows, at most %d", n_alive, kBookMax);
+  CMBPO_REQUIRE(!r->use_host_budget, "cmbpo_rollout_book_pre: the cross-shard budget exchange uses the separate kernels");
+  CMBPO_REQUIRE(r->ptr < r->T, "cmbpo_rollout_book_pre: buffer full (ptr %d == T)", r->ptr);
+  CMBPO_REQUIRE(r->dkl_t && r->dkl_acc && r->cur_obs && r->act_t && r->logp_t && r->mu_t && r->ls_t && r->v_t && r->vc_t &&
+                    r->rew_t && r->cost_t && r->epv_t,
+                "cmbpo_rollout_book_pre: NULL step array");
+  CMBPO_REQUIRE(r->obs_buf && r->act_buf && r->mu_buf && r->ls_buf && r->rew_buf && r->val_buf && r->cost_buf && r->cval_buf &&
+                    r->logp_buf && r->adv_buf && r->ret_buf && r->cadv_buf && r->cret_buf,
+                "cmbpo_rollout_book_pre: NULL buffer");
+  if (n_alive == 0) return CMBPO_OK;
+  hipLaunchKernelGGL(book_pre_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r);
+  hipLaunchKernelGGL(store_vec_kernel, dim3(cmbpo_ceil_div(n_alive, kStoreRows)), dim3(256), 0, (hipStream_t)stream, *r);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+extern "C" int cmbpo_rollout_book_post(const cmbpo_rollout_t *r, int n_alive, void *stream) {
+  if (int rc = check_rollout(r, "cmbpo_rollout_book_post")) return rc;
+  CMBPO_REQUIRE(n_alive >= 0 && n_alive <= kBookMax, "cmbpo_rollout_book_post: %d alive rows, at most %d", n_alive, kBookMax);
+  CMBPO_REQUIRE(r->v_n && r->vc_n && r->term_t && r->rew_buf && r->val_buf && r->cost_buf && r->cval_buf && r->adv_buf &&
+                    r->ret_buf && r->cadv_buf && r->cret_buf,
+                "cmbpo_rollout_book_post: NULL array");
+  hipLaunchKernelGGL(book_post_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+// the step's counters and accumulators (32 int32 + 32 float64, contiguous) into host memory, then wait for the stream:
+// the one host synchronisation of a rollout step, as a single call (h_out384: 384 bytes, pinned for a true async copy)
+extern "C" int cmbpo_rollout_read_scalars(const cmbpo_rollout_t *r, void *h_out384, void *stream) {
+  CMBPO_REQUIRE(r && r->iscal && r->dscal && h_out384, "cmbpo_rollout_read_scalars: NULL argument");
+  CMBPO_REQUIRE(reinterpret_cast<const char *>(r->dscal) == reinterpret_cast<const char *>(r->iscal) + 128,
+                "cmbpo_rollout_read_scalars: iscal[32] and dscal[32] must be one 384-byte block");
+  CMBPO_HIP_CHECK(hipMemcpyAsync(h_out384, r->iscal, 384, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  CMBPO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   return CMBPO_OK;
 }
 

@@ -23,15 +23,23 @@ extern "C" int cmbpo_rollout_step(const cmbpo_rollout_t *r, int n_alive, cmbpo_m
                                r->alive_idx, nullptr, n_alive, w(r->next_obs), w(r->rew_t), const_cast<uint8_t *>(r->term_t), w(r->cost_t),
                                w(r->dkl_t), w(r->epv_t), nullptr, stream)))
     return rc;
-  if ((rc = cmbpo_rollout_decide(r, stream))) return rc;
-  if ((rc = cmbpo_rollout_finish(r, 0, stream))) return rc;
-  if ((rc = cmbpo_rollout_store(r, stream))) return rc;
+  if (n_alive <= cmbpo_rollout_book_pre_max_rows() && !r->use_host_budget) {
+    if ((rc = cmbpo_rollout_book_pre(r, n_alive, stream))) return rc;     // decide + finish(PRE) + store in one launch
+  } else {
+    if ((rc = cmbpo_rollout_decide(r, stream))) return rc;
+    if ((rc = cmbpo_rollout_finish(r, 0, stream))) return rc;
+    if ((rc = cmbpo_rollout_store(r, stream))) return rc;
+  }
   if (cmbpo_critic_pair_supported(v, vc)) {      // both critics in one launch (csrc/critic_f16.hip)
     if ((rc = cmbpo_critic_pair_predict(v, vc, r->next_obs, r->obs_dim, r->alive_idx, nullptr, n_alive, w(r->v_n), w(r->vc_n), stream)))
       return rc;
   } else {
     if ((rc = cmbpo_ens_predict_mean(v, r->next_obs, r->obs_dim, r->alive_idx, nullptr, n_alive, w(r->v_n), stream))) return rc;
     if ((rc = cmbpo_ens_predict_mean(vc, r->next_obs, r->obs_dim, r->alive_idx, nullptr, n_alive, w(r->vc_n), stream))) return rc;
+  }
+  if (n_alive <= cmbpo_rollout_book_pre_max_rows() && !r->use_host_budget) {
+    if ((rc = cmbpo_rollout_book_post(r, n_alive, stream))) return rc;    // finish(POST) + compaction in one launch
+    return 1;                                                              // the alive list has been rebuilt: swap it
   }
   return cmbpo_rollout_finish(r, 1, stream);
 }

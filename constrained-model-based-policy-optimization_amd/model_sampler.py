@@ -56,9 +56,11 @@ class ModelSampler:
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(self._seed)
         self._elites = None
+        self._handles = None
 
     def set_policy(self, policy):
         self.policy = policy
+        self._handles = None
 
     def set_logger(self, logger):
         self.logger = logger
@@ -157,6 +159,7 @@ class ModelSampler:
         elites = np.asarray(self.env._model.elite_inds, dtype=np.int32)
         self._elites = torch.as_tensor(elites, device=self.device)
         self._draws = None
+        self._handles = None
 
     def _scatter(self, compact, idx, width=None, dtype=torch.float32):
         """Test hook: a draw given in the reference's compact (alive-only) order -> slot order."""
@@ -179,6 +182,11 @@ class ModelSampler:
             # this shard has nothing left but the others may: keep the collectives of the step matched
             return self._idle_step(max_samples)
         assert pool.n_alive > 0                    # reset before sampling !
+        if not sharded and eps is None and model_inds is None and env.kernel_events is None:
+            if torch.cuda.current_device() != self.device.index:
+                with torch.cuda.device(self.device):
+                    return self._sample_fast(max_samples)
+            return self._sample_fast(max_samples)
         self._n_episodes += 1
         t, rs = pool.t, pool.rs
         n, B, A = pool.n_alive, self.batch_size, pool.act_dim
@@ -189,10 +197,7 @@ class ModelSampler:
                 # instead of per step: at small rollout batches a step is a chain of launch latencies)
                 ck = getattr(self, "_draws", None)
                 if ck is None or ck[0] >= ck[1].shape[0] or ck[1].shape[1] != B:
-                    K = max(1, min(8, int(2 ** 28 // max(B * A * 4, 1))))
-                    e_ck = torch.randn((K, B, A), generator=self._gen, dtype=torch.float32, device=self.device)
-                    d_ck = torch.randint(0, len(self._elites), (K, B), generator=self._gen, device=self.device)
-                    ck = self._draws = [0, e_ck, self._elites[d_ck]]
+                    ck = self._draw_chunk()
                 k = ck[0]
                 ck[0] = k + 1
             if eps is None:
@@ -212,13 +217,17 @@ class ModelSampler:
             rs.max_path_length = self._max_path_length
             rs.use_host_budget = 0
             exchange = sharded and rs.max_samples != 0      # the reference's `if max_samples:` (negative budgets count)
+            compacted = False
             if not exchange and env.kernel_events is None:
                 # the whole step in one call: at small rollout batches a step is bound by host latency
-                _lib.check(_lib.lib().cmbpo_rollout_step(
+                rc = _lib.lib().cmbpo_rollout_step(
                     C.byref(rs), n, pol.actor.mlp.handle, env._model.mlp.handle, pol.v.mlp.handle, pol.vc.mlp.handle,
                     env._task_id, env._model.num_nets, eps_t.data_ptr(), inds_t.data_ptr(),
-                    self._scratch[0].data_ptr(), self._scratch[1].data_ptr(), _lib.current_stream()),
-                    "cmbpo_rollout_step")
+                    self._scratch[0].data_ptr(), self._scratch[1].data_ptr(), _lib.current_stream())
+                if rc == 1:         # small batch: finish(POST) and the compaction ran inside the call
+                    compacted = True
+                else:
+                    _lib.check(rc, "cmbpo_rollout_step")
             else:
                 # policy: pi, logp, mu, log_std at the current observations
                 pol.actor.forward_device(t["cur_obs"], eps_t,
@@ -242,7 +251,9 @@ class ModelSampler:
                 pool._call("cmbpo_rollout_finish", 1)
             # the host sync of the step: counters of what finished / was stored + the accumulators
             isc, dsc = self._read_scalars()
-            if int(isc[_lib.I_N_FIN_PRE]) + int(isc[_lib.I_N_FIN_POST]) > 0:
+            if compacted:
+                pool.swap("alive_idx", "alive_idx_out")
+            elif int(isc[_lib.I_N_FIN_PRE]) + int(isc[_lib.I_N_FIN_POST]) > 0:
                 pool._call("cmbpo_rollout_compact")      # the alive list only changes when a branch finished
                 pool.swap("alive_idx", "alive_idx_out")
                 pool.sync_counters()
@@ -262,6 +273,67 @@ class ModelSampler:
             alive_ratio = alive / self.batch_size
         info = {"alive_ratio": alive_ratio, "ensemble_dkl_path": t["dkl_t"], "cost": t["cost_t"]}
         # after the swap the step's next_obs is the new cur_obs
+        return t["cur_obs"], t["rew_t"], t["term_t"], info
+
+    def _draw_chunk(self):
+        """Action noise and elite picks for several steps at a time (three torch launches per chunk instead of per step:
+        at small rollout batches a step is a chain of launch latencies).  Returns the chunk list
+        [next step, eps [K, B, A], elite indices [K, B]]."""
+        B, A = self.batch_size, self.pool.act_dim
+        K = max(1, min(8, int(2 ** 28 // max(B * A * 4, 1))))
+        e_ck = torch.randn((K, B, A), generator=self._gen, dtype=torch.float32, device=self.device)
+        d_ck = torch.randint(0, len(self._elites), (K, B), generator=self._gen, device=self.device)
+        self._draws = [0, e_ck, self._elites[d_ck]]
+        return self._draws
+
+    def _sample_fast(self, max_samples):
+        """sample() on one rank with the sampler's own draws: the whole step is ONE C call (cmbpo_rollout_step) plus the
+        read of the step's counters.  Same results as the general path below -- at the shipped configurations' 1e3 - 1e4
+        branches a step is ~100 us of kernels, so the host side is kept to pointer arithmetic."""
+        pool, env, pol = self.pool, self.env, self.policy
+        self._n_episodes += 1
+        t, rs = pool.t, pool.rs
+        n, B, A = pool.n_alive, self.batch_size, pool.act_dim
+        ck = self._draws
+        if ck is None or ck[0] >= ck[1].shape[0] or ck[1].shape[1] != B:
+            ck = self._draw_chunk()
+        k = ck[0]
+        ck[0] = k + 1
+        eps_ptr = ck[1].data_ptr() + k * B * A * 4
+        inds_ptr = ck[2].data_ptr() + k * B * ck[2].element_size()
+        if getattr(self, "_scratch", None) is None or self._scratch[0].shape[1] != B:
+            E, O = env._model.num_nets, env.output_dim
+            self._scratch = (torch.empty((E, B, O), dtype=torch.float32, device=self.device),
+                             torch.empty((E, B, O), dtype=torch.float32, device=self.device))
+            self._handles = None
+        if getattr(self, "_handles", None) is None:
+            self._handles = (pol.actor.mlp.handle, env._model.mlp.handle, pol.v.mlp.handle, pol.vc.mlp.handle,
+                             self._scratch[0].data_ptr(), self._scratch[1].data_ptr())
+        h = self._handles
+        rs.max_samples = int(max_samples) if max_samples else 0
+        rs.dkl_lim = float(self.dkl_lim)
+        rs.max_path_length = self._max_path_length
+        rs.use_host_budget = 0
+        stream = _lib.current_stream()
+        rc = _lib.lib().cmbpo_rollout_step(C.byref(rs), n, h[0], h[1], h[2], h[3], env._task_id, env._model.num_nets,
+                                           eps_ptr, inds_ptr, h[4], h[5], stream)
+        if rc != 1:
+            _lib.check(rc, "cmbpo_rollout_step")
+        isc, dsc = self._read_scalars()         # the host sync of the step
+        if rc == 1:                             # small batch: finish(POST) and the compaction ran inside the call
+            pool.swap("alive_idx", "alive_idx_out")
+        elif int(isc[_lib.I_N_FIN_PRE]) + int(isc[_lib.I_N_FIN_POST]) > 0:
+            pool._call("cmbpo_rollout_compact")
+            pool.swap("alive_idx", "alive_idx_out")
+            pool.sync_counters()
+        pool.swap("cur_obs", "next_obs")
+        pool.swap("v_t", "v_n")
+        pool.swap("vc_t", "vc_n")
+        pool.ptr += 1
+        rs.ptr = pool.ptr
+        self._host["total_samples"] = float(dsc[_lib.D_TOTAL_SAMPLES])
+        self._host["total_dkl"] = float(dsc[_lib.D_TOTAL_DKL])
+        info = {"alive_ratio": pool.n_alive / self.batch_size, "ensemble_dkl_path": t["dkl_t"], "cost": t["cost_t"]}
         return t["cur_obs"], t["rew_t"], t["term_t"], info
 
     def _idle_step(self, max_samples):

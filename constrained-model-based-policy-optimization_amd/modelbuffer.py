@@ -135,8 +135,14 @@ class ModelBuffer:
     # ------------------------------------------------------------------------------------------
     def read_scalars(self):
         """One small D2H copy (the host sync of a step): (int32 counters, float64 accumulators)."""
-        raw = self.t["scal_bytes"].cpu()
-        isc, dsc = raw[:128].view(torch.int32).numpy(), raw[128:].view(torch.float64).numpy()
+        if getattr(self, "_scal_host", None) is None:
+            # pinned once: the copy is a true async D2H and the NumPy views below never change
+            self._scal_host = torch.empty(384, dtype=torch.uint8, pin_memory=True)
+            self._scal_views = (self._scal_host[:128].view(torch.int32).numpy(), self._scal_host[128:].view(torch.float64).numpy())
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().cmbpo_rollout_read_scalars(C.byref(self.rs), self._scal_host.data_ptr(), _lib.current_stream()),
+                       "cmbpo_rollout_read_scalars")
+        isc, dsc = self._scal_views[0].copy(), self._scal_views[1].copy()     # (the pinned block is rewritten by the next read)
         self._n_alive = int(isc[_lib.I_N_ALIVE])
         self._size = int(isc[_lib.I_SIZE])
         return isc, dsc

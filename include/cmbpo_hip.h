@@ -279,6 +279,19 @@ int cmbpo_rollout_compact(const cmbpo_rollout_t *r, void *stream);
  * cmbpo_ens_forward -> cmbpo_fakeenv_post -> decide -> finish(PRE) -> store -> cmbpo_ens_predict_mean x 2 at next_obs ->
  * finish(POST), every buffer taken from *r (slot-indexed d_eps [B, act], d_elite [B]; scratch d_mean / d_var
  * [E, B, obs + 1]).  n_alive = the host's copy of iscal[CMBPO_I_N_ALIVE]. */
+/* Small rollout batches: decide + finish(PRE) + store (+ its statistics) as one single-workgroup launch for up to
+ * cmbpo_rollout_book_pre_max_rows() alive rows (same decisions and per-branch arithmetic as the separate calls;
+ * single-rank path).  cmbpo_rollout_step uses it by itself. */
+int cmbpo_rollout_book_pre_max_rows(void);
+int cmbpo_rollout_book_pre(const cmbpo_rollout_t *r, int n_alive, void *stream);
+/* ... and finish(POST) + the compaction likewise: the ordered alive list of the survivors is ALWAYS written to
+ * alive_idx_out (iscal[CMBPO_I_N_ALIVE] updated), so the host swaps the two lists after every such step.
+ * cmbpo_rollout_step returns 1 (instead of 0) when it took this path. */
+int cmbpo_rollout_book_post(const cmbpo_rollout_t *r, int n_alive, void *stream);
+/* The step's counters and accumulators (iscal[32] | dscal[32], one 384-byte block) into host memory + a stream
+ * synchronisation: the one host sync of a rollout step (the reference's per-step `alive_ratio`,
+ * samplers/model_sampler.py:371-375). */
+int cmbpo_rollout_read_scalars(const cmbpo_rollout_t *r, void *h_out384, void *stream);
 int cmbpo_rollout_step(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy, cmbpo_mlp_t *model,
                        cmbpo_mlp_t *v, cmbpo_mlp_t *vc, int task, int ensemble, const float *d_eps,
                        const int32_t *d_elite, float *d_mean, float *d_var, void *stream);

@@ -42,3 +42,22 @@ def test_strong_scaling_shards_are_a_partition():
         assert blocks[0][0] == 0 and blocks[-1][1] == total
         assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
         assert max(h - l for l, h in blocks) - min(h - l for l, h in blocks) <= 1
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_gpus2_runs_the_rollout_on_two_ranks():
+    """The launcher with the real kernels: two ranks (both on this box's one GPU, gloo instead of RCCL -- only the
+    transport differs) run the sharded rollout phase, weak and strong scaling."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    for extra, total in ((["--branches", "3000"], 6000), (["--branches", "3000", "--scaling", "strong"], 3000)):
+        r = _run(["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-extras", "--maxroll", "6"] + extra,
+                 {"CMBPO_DIST_BACKEND": "gloo"})
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+        assert out["n_gpus"] == 2 and out["config"]["branches_total"] == total
+        assert out["value"] > 0 and out["config"]["samples_per_step"] == total * 5      # every branch lives 5 steps

@@ -256,7 +256,8 @@ class ModelSampler:
             elif int(isc[_lib.I_N_FIN_PRE]) + int(isc[_lib.I_N_FIN_POST]) > 0:
                 pool._call("cmbpo_rollout_compact")      # the alive list only changes when a branch finished
                 pool.swap("alive_idx", "alive_idx_out")
-                pool.sync_counters()
+                # the survivors' count follows from the counters just read: no second host synchronisation
+                pool._n_alive = n - int(isc[_lib.I_N_FIN_PRE]) - int(isc[_lib.I_N_FIN_POST])
             pool.swap("cur_obs", "next_obs")
             pool.swap("v_t", "v_n")
             pool.swap("vc_t", "vc_n")
@@ -325,7 +326,8 @@ class ModelSampler:
         elif int(isc[_lib.I_N_FIN_PRE]) + int(isc[_lib.I_N_FIN_POST]) > 0:
             pool._call("cmbpo_rollout_compact")
             pool.swap("alive_idx", "alive_idx_out")
-            pool.sync_counters()
+            # the survivors' count follows from the counters just read: no second host synchronisation
+            pool._n_alive = n - int(isc[_lib.I_N_FIN_PRE]) - int(isc[_lib.I_N_FIN_POST])
         pool.swap("cur_obs", "next_obs")
         pool.swap("v_t", "v_n")
         pool.swap("vc_t", "vc_n")

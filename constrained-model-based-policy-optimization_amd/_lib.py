@@ -115,6 +115,8 @@ SIGNATURES.update({
     "cmbpo_pi_fvp": (_i, [_p, _bp, _p, _p, _p]),
     "cmbpo_pi_keep_activations": (_i, [_p, _i]),
     "cmbpo_pi_saved_activation_uses": (C.c_long, [_p]),
+    "cmbpo_set_pi_matrix_path": (None, [_i]),
+    "cmbpo_get_pi_matrix_path": (_i, []),
     "cmbpo_pi_eval": (_i, [_p, _bp, _p, _p]),
     "cmbpo_cg_init": (_i, [_i, _p, _p, _p, _p, _p, _p]),
     "cmbpo_cg_step": (_i, [_i, _p, C.c_double, C.c_float, _p, _p, _p, _p, _p]),

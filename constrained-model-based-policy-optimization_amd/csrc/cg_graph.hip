@@ -25,6 +25,7 @@ struct CgKey {
   int iters, P;
   hipStream_t s;
   const void *act;   // saved activations the captured Fisher-vector products read (or NULL)
+  int path;          // arithmetic path of the captured kernels (cmbpo_set_pi_matrix_path)
 };
 
 struct CgGraph {
@@ -52,6 +53,7 @@ extern "C" int cmbpo_pi_cg_solve(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, const
   k.h = h; memcpy(&k.b, b, sizeof(k.b)); k.vec = d_vec; k.x = d_x; k.r = d_r; k.p = d_p; k.scal = d_scal;
   k.inv_n = inv_n; k.damping = damping; k.iters = iters; k.P = cmbpo_pi_num_params(h); k.s = (hipStream_t)stream;
   k.act = cmbpo_pi_act_token(h, b);
+  k.path = cmbpo_get_pi_matrix_path();
   if (int rc = cmbpo_cg_init(k.P, d_b, d_x, d_r, d_p, d_scal, stream)) return rc;
   if (int rc = iteration(h, k)) return rc;            // eager: also performs any one-time kernel attribute set-up
   if (iters == 1) return cmbpo_pi_cg_commit(d_scal, stream);

@@ -22,6 +22,15 @@ sys.path.insert(0, GOLD)
 from oracle import refupdate  # noqa: E402
 
 
+@pytest.fixture(autouse=True, params=[1, 0], ids=["splitf16", "fp32mfma"])
+def pi_path(request, hip_lib):
+    """Every test of this file on both arithmetic paths of the 128 x 128 products (cmbpo_set_pi_matrix_path)."""
+    before = hip_lib.cmbpo_get_pi_matrix_path()
+    hip_lib.cmbpo_set_pi_matrix_path(request.param)
+    yield request.param
+    hip_lib.cmbpo_set_pi_matrix_path(before)
+
+
 def _need_gpu():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")

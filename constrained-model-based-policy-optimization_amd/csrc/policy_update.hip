@@ -59,10 +59,10 @@ struct PiDims {
 struct PiPack {          // device pointers into the handle's blob
   const f32x4 *F0, *F1, *F2, *B1, *B2;
   const float *b0, *b1, *b2, *ls;
-  // the three-term f16 path (see "f16 images" below): W1 as the forward (F1h) and the backward (B1h) A operand, each row
-  // lifted by its own power of two; iF1 / iB1 = the inverse lifts [128]
-  const u32x4 *F1h, *B1h;
-  const float *iF1, *iB1;
+  // the three-term f16 path (see "f16 images" below): every matrix as the A operand of its forward (F) and backward (B)
+  // product, lifted by one power of two per matrix: lift[L_*] and, 8 floats on, its inverse
+  const u32x4 *F0h, *F1h, *F2h, *B1h, *B2h;
+  const float *lift;
   const float *mx;     // {max |W0|, max |b0|, max |W2|, 0}
 };
 
@@ -89,38 +89,70 @@ struct PiArgs {
 struct PackPiece {
   int dst_off, src_off, n_lim, k_lim, sn, sk, kg, count;   // count = floats written (incl. zero padding)
 };
+// ---- f16 images ------------------------------------------------------------------------------------------
+// pi_kernel_h runs every matrix product as three f16 MFMAs on two-piece operands (f16_split.h).  The matrix side is split
+// once per pack: image[n-tile][k-slab][piece 2][lane 64] of 8 halves, row n = 32 nt + (lane & 31), k = 16 slab +
+// 8 (lane >> 5) + e, every element lifted by S = pow2_lift(max |A|) (one power of two per matrix: an element keeps its
+// full 22 bits while it is within 2^-12 of the matrix maximum, and loses them one by one below); rows / columns past the
+// matrix are zero.
+enum { L_F0 = 0, L_F1, L_F2, L_B1, L_B2 };
+struct H16Img {
+  int src_off, sn, sk, n_lim, k_lim;   // A[n][k] = flat[src_off + n sn + k sk], n < n_lim, k < k_lim
+  int n_tiles, slabs;
+  int dst_off;                         // u32x4 from the pack's f16 block
+  int lift_idx;                        // L_*
+};
+// layout of a pack's f16 block (u32x4 units); the input layer is laid out for its largest width (64 inputs, 4 slabs)
+constexpr int H16_F0 = 0, H16_F1 = H16_F0 + 4 * 4 * 128, H16_B1 = H16_F1 + 4 * 8 * 128, H16_F2 = H16_B1 + 4 * 8 * 128,
+              H16_B2 = H16_F2 + 8 * 128, H16_INV = H16_B2 + 4 * 2 * 128;
+constexpr int INV_LIFT = 0, INV_MX = 16, INV_FLOATS = 20;   // lift[8] | 1 / lift[8] | {max |W0|, max |b0|, max |W2|, 0}
+constexpr int H16_PACK = H16_INV + INV_FLOATS / 4;
+
 struct PackPlan {
   PackPiece piece[9];
   int total;
-  int nb32;      // workgroups of the fp32 part; then one for the maxima, then the f16 images, 8 workgroups each
-  int oW1;       // offset of W1 in the flat vector
+  int nb32;      // workgroups of the fp32 part; then one for the maxima, then the f16 images
   int oW0, nW0, ob0, oW2, nW2;   // the pieces whose largest magnitudes bound dh1 and delta2
+  H16Img img[5];
+  int img_blk[6];                // first workgroup of each image, relative to nb32 + 1
+  int n_img;
 };
 
-// ---- f16 images ------------------------------------------------------------------------------------------
-// The 128 x 128 products of the update (h1 W1, h1 dW1, dh1 W1, delta2 W1^T and the W1 weight gradient) run as three f16
-// MFMAs on two-piece operands (f16_split.h).  The matrix side is split once per pack: image[nt][slab 8][piece 2][lane 64]
-// of 8 halves, row n = 32 nt + (lane & 31) lifted by S_n = pow2_lift(max_k |A[n][k]|), k = 16 slab + 8 (lane >> 5) + e.
-// The activation side is split as it is read from its fp32 row image in LDS, with a power of two per tile.
-constexpr int H16_MAT = 4 * 8 * 2 * 64;      // u32x4 per image
-constexpr int H16_PACK = 2 * H16_MAT + 64 + 1;   // F1h | B1h | inverse lifts (2 x 128 floats) | {max |W0|, max |b0|, max |W2|, 0}
-
-__device__ __forceinline__ void pack_f16_part(u32x4 *dst16, const float *w1, int m, int t) {
-  const int lane = t & 63, s = (t >> 6) & 7, nt = t >> 9;
-  const int n = nt * 32 + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
-  // m == 0: A[n][k] = W1[k][n] (forward);  m == 1: A[n][k] = W1[n][k] (backward)
-  const int sn = m == 0 ? 1 : HID, sk = m == 0 ? HID : 1;
-  const float *row = w1 + (size_t)n * sn;
+__device__ __forceinline__ void pack_f16_part(u32x4 *dst16, const float *flat, const H16Img &im, int blk) {
+  // every workgroup of an image first finds the matrix's largest magnitude (16 K elements from L2: cheaper than a launch)
+  __shared__ float red[256];
+  const float *src = flat + im.src_off;
   float mx = 0.0f;
-  for (int k = 0; k < HID; ++k) mx = fmaxf(mx, fabsf(row[(size_t)k * sk]));
-  const float S = pow2_lift(mx);
+  for (int e = threadIdx.x; e < im.n_lim * im.k_lim; e += 256) {
+    const int n = e / im.k_lim, k = e - n * im.k_lim;
+    mx = fmaxf(mx, fabsf(src[(size_t)n * im.sn + (size_t)k * im.sk]));
+  }
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  const float S = pow2_lift(red[0]);
+  if (blk == 0 && threadIdx.x == 0) {
+    float *lift = reinterpret_cast<float *>(dst16 + H16_INV) + INV_LIFT;
+    lift[im.lift_idx] = S;
+    lift[8 + im.lift_idx] = 1.0f / S;
+  }
+  const int t = blk * 256 + threadIdx.x;
+  const int lane = t & 63, s = (t >> 6) % im.slabs, nt = (t >> 6) / im.slabs;
+  if (nt >= im.n_tiles) return;
+  const int n = nt * 32 + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
+  const float *row = src + (size_t)n * im.sn;
   union { _Float16 hv[8]; u32x4 q; } p1, p2;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) split_h(row[(size_t)(k0 + e) * sk] * S, p1.hv[e], p2.hv[e]);
-  u32x4 *img = dst16 + (size_t)m * H16_MAT + (size_t)((nt * 8 + s) * 2) * 64 + lane;
+  for (int e = 0; e < 8; ++e) {
+    const float v = (n < im.n_lim && k0 + e < im.k_lim) ? row[(size_t)(k0 + e) * im.sk] * S : 0.0f;
+    split_h(v, p1.hv[e], p2.hv[e]);
+  }
+  u32x4 *img = dst16 + im.dst_off + (size_t)((nt * im.slabs + s) * 2) * 64 + lane;
   img[0] = p1.q;
   img[64] = p2.q;
-  if (s == 0 && lane < 32) reinterpret_cast<float *>(dst16 + 2 * H16_MAT)[m * HID + n] = 1.0f / S;
 }
 
 __device__ __forceinline__ void pack_max_part(u32x4 *dst16, const float *flat, const PackPlan &plan) {
@@ -136,7 +168,8 @@ __device__ __forceinline__ void pack_max_part(u32x4 *dst16, const float *flat, c
       for (int k = 0; k < 3; ++k) red[k][threadIdx.x] = fmaxf(red[k][threadIdx.x], red[k][threadIdx.x + o]);
     __syncthreads();
   }
-  if (threadIdx.x < 4) reinterpret_cast<float *>(dst16 + 2 * H16_MAT + 64)[threadIdx.x] = threadIdx.x < 3 ? red[threadIdx.x][0] : 0.0f;
+  if (threadIdx.x < 4)
+    reinterpret_cast<float *>(dst16 + H16_INV)[INV_MX + threadIdx.x] = threadIdx.x < 3 ? red[threadIdx.x][0] : 0.0f;
 }
 
 __global__ void pack_all_kernel(float *dst, const float *flat, const PackPlan plan, u32x4 *dst16) {
@@ -146,7 +179,9 @@ __global__ void pack_all_kernel(float *dst, const float *flat, const PackPlan pl
   }
   if ((int)blockIdx.x > plan.nb32) {
     const int b = blockIdx.x - plan.nb32 - 1;
-    pack_f16_part(dst16, flat + plan.oW1, b >> 3, (b & 7) * 256 + threadIdx.x);
+    int m = 0;
+    while (m + 1 < plan.n_img && b >= plan.img_blk[m + 1]) ++m;
+    pack_f16_part(dst16, flat, plan.img[m], b - plan.img_blk[m]);
     return;
   }
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -169,164 +204,10 @@ __global__ void pack_all_kernel(float *dst, const float *flat, const PackPlan pl
   dst[pc.dst_off + idx] = v;
 }
 
-// ---- the activation side of the f16 path ---------------------------------------------------------------------
-// An image that feeds a 128-deep product (h1, dh1, delta2) lives in LDS as its two f16 pieces, split ONCE by the wave that
-// produces it: row b = [p1: 128 halves | p2: 128 halves | 8 halves of padding] -- the footprint and the bank pattern of the
-// fp32 row [RS] it replaces.  The lift of an image is a power of two known before it is produced: 2^14 for tanh outputs, and
-// for dh1 / delta2 the lift of an upper bound (largest |x| of the tile x D x max |dW0| + max |db0|; largest |cotangent| x A
-// x max |W2|) -- a lift below the optimum costs nothing until the second piece leaves the f16 range, ~2^10 further down.
-constexpr float T_TANH = 16384.0f;      // |tanh| <= 1
-constexpr float T_TANH_INV = 1.0f / 16384.0f;
-constexpr int RSH = 2 * RS;             // row stride of a two-piece image, in halves
-constexpr int P2H = HID;                // offset of the second piece inside a row, in halves
-
-__device__ __forceinline__ float pow2_inv(float t) {   // exact inverse of a power of two in [2^-126, 2^126]
-  return __uint_as_float(0x7F000000u - __float_as_uint(t));
-}
-
-// four floats x t -> two packed f16 pieces (p1 = f16(x t), p2 = f16(x t - p1): one v_fma_mix each, see f16_split.h)
-__device__ __forceinline__ void split4(const float (&x)[4], float t, unsigned (&q1)[2], unsigned (&q2)[2]) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    unsigned a, b;   // (the low halves are written first: "=&v", the registers need no initial value)
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(a) : "v"(x[2 * i]), "v"(t));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(a) : "v"(x[2 * i + 1]), "v"(t));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(b) : "v"(x[2 * i]), "v"(t), "v"(a));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(b) : "v"(x[2 * i + 1]), "v"(t), "v"(a));
-    q1[i] = a;
-    q2[i] = b;
-  }
-}
-
-// accumulator tile (rows n_base.., cols b) x t -> the two-piece image
-__device__ __forceinline__ void store_tile_H(const f32x16 &v, int n_base, _Float16 *img, float t, int lane) {
-  const int j = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float x[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-    unsigned q1[2], q2[2];
-    split4(x, t, q1, q2);
-    _Float16 *dst = img + j * RSH + n_base + 8 * q + 4 * h;
-    *reinterpret_cast<uint2 *>(dst) = make_uint2(q1[0], q1[1]);
-    *reinterpret_cast<uint2 *>(dst + P2H) = make_uint2(q2[0], q2[1]);
-  }
-}
-
-// the tile rows n_base.. of this wave's columns, as p1 + p2 (= value x lift, exact in fp32)
-__device__ __forceinline__ f32x16 load_tile_H(const _Float16 *img, int n_base, int lane) {
-  const int j = lane & 31, h = lane >> 5;
-  f32x16 v;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const _Float16 *src = img + j * RSH + n_base + 8 * q + 4 * h;
-    const f16x4 a = *reinterpret_cast<const f16x4 *>(src), b = *reinterpret_cast<const f16x4 *>(src + P2H);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[4 * q + e] = (float)a[e] + (float)b[e];
-  }
-  return v;
-}
-
-// largest |value| a thread holds -> one LDS word per tile (non-negative floats order like their bits)
-__device__ __forceinline__ void thread_max_put(float m, unsigned *slot, int lane) {
-  m = fmaxf(m, __shfl_xor(m, 1, 64));
-  m = fmaxf(m, __shfl_xor(m, 2, 64));
-  if ((lane & 3) == 0) atomicMax(slot, __float_as_uint(m));
-}
-
-// A operand ring: RW slabs of a matrix image in registers, refilled slab by slab with the NEXT product's matrix, so that
-// every L2 read is requested a whole product (8 slabs, 24 MFMAs) before its first use
-template <int RW>
-struct WRing {
-  u32x4 a[RW][2];
-};
-template <int RW>
-__device__ __forceinline__ void ring_fill(WRing<RW> &R, const u32x4 *img, int lane) {
-#pragma unroll
-  for (int s = 0; s < RW; ++s) {
-    R.a[s][0] = (img + (2 * s) * 64)[lane];        // (scalar base + constant first: saddr addressing, one VGPR offset)
-    R.a[s][1] = (img + (2 * s + 1) * 64)[lane];
-  }
-}
-
-// acc[n][b] += sum_k A[n][k] X[b][k] t S_n   (K = 128): A = this wave's n-tile of image `cur` (slabs 0 .. RW-1 already in
-// the ring), X = a two-piece image in LDS.  Leaves slabs 0 .. RW-1 of `nxt` in the ring (NEXT == true).
-template <int RW, bool NEXT>
-__device__ __forceinline__ void gemm_h(f32x16 &acc, WRing<RW> &R, const u32x4 *cur, const u32x4 *nxt, const _Float16 *X,
-                                       int lane, int lane_t) {
-  const _Float16 *xp = X + (lane & 31) * RSH + 8 * (lane >> 5);
-  u32x4 b1[2], b2[2];
-  b1[0] = *reinterpret_cast<const u32x4 *>(xp);
-  b2[0] = *reinterpret_cast<const u32x4 *>(xp + P2H);
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    if (s + 1 < 8) {
-      b1[(s + 1) & 1] = *reinterpret_cast<const u32x4 *>(xp + 16 * (s + 1));
-      b2[(s + 1) & 1] = *reinterpret_cast<const u32x4 *>(xp + 16 * (s + 1) + P2H);
-    }
-    const f16x8 a1 = __builtin_bit_cast(f16x8, R.a[s % RW][0]), a2 = __builtin_bit_cast(f16x8, R.a[s % RW][1]);
-    mm3(acc, a1, a2, __builtin_bit_cast(f16x8, b1[s & 1]), __builtin_bit_cast(f16x8, b2[s & 1]));
-    if (s + RW < 8) {
-      R.a[s % RW][0] = (cur + (2 * (s + RW)) * 64)[lane_t];
-      R.a[s % RW][1] = (cur + (2 * (s + RW) + 1) * 64)[lane_t];
-    } else if constexpr (NEXT) {
-      R.a[s % RW][0] = (nxt + (2 * (s + RW - 8)) * 64)[lane_t];
-      R.a[s % RW][1] = (nxt + (2 * (s + RW - 8) + 1) * 64)[lane_t];
-    }
-    __builtin_amdgcn_sched_barrier(0);   // left alone, the scheduler lifts every slab's reads to the top
-  }
-}
-
-// the two-piece fragment of eight samples b = b0 + e of column c of a two-piece image (the K = sample operand of a weight
-// gradient): 16-bit reads straight into the halves of the operand registers
-__device__ __forceinline__ void frag_T(const _Float16 *img, int b0, int c, f16x8 &p1, f16x8 &p2) {
-  const _Float16 *q = img + b0 * RSH + c;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    p1[e] = q[e * RSH];
-    p2[e] = q[e * RSH + P2H];
-  }
-}
-
-// g[J][i][j] += sum_b X[b][i0 + i] Y[b][32 J + j], J = 0 .. 3   (K = the 32 samples of the tile); X, Y two-piece images;
-// colsum += sum_b Y[b][32 jsum + j] (lifted; the two lane halves hold the two halves of the samples)
-__device__ __forceinline__ void wgrad_h(f32x16 (&g)[4], const _Float16 *X, int i0, const _Float16 *Y, float unscale, float y_unscale,
-                                        int jsum, float &colsum, int lane) {
-  const int i = lane & 31, b0 = 8 * (lane >> 5);
-  f16x8 a1[2], a2[2];
-  frag_T(X, b0, i0 + i, a1[0], a2[0]);
-  frag_T(X, b0 + 16, i0 + i, a1[1], a2[1]);
-#pragma unroll
-  for (int J = 0; J < 4; ++J) {
-    f16x8 b1[2], b2[2];
-    frag_T(Y, b0, 32 * J + i, b1[0], b2[0]);
-    frag_T(Y, b0 + 16, 32 * J + i, b1[1], b2[1]);
-    f32x16 tmp;
-    zero(tmp);
-    mm3(tmp, a1[0], a2[0], b1[0], b2[0]);
-    mm3(tmp, a1[1], a2[1], b1[1], b2[1]);
-    if (J == jsum) {
-      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-      const f16x2 one = {(_Float16)1.0f, (_Float16)1.0f};
-      float cs = 0.0f;
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const f16x2 u = {b2[s][2 * e], b2[s][2 * e + 1]}, w = {b1[s][2 * e], b1[s][2 * e + 1]};
-          cs = __builtin_amdgcn_fdot2(u, one, cs, false);
-          cs = __builtin_amdgcn_fdot2(w, one, cs, false);
-        }
-      colsum += cs * y_unscale;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) g[J][r] = __builtin_fmaf(tmp[r], unscale, g[J][r]);
-  }
-}
-
 // Every activation image lives in LDS ONCE, in the row layout [sample][RS] (RS / 4 odd): it is the B operand of
 // the forward / JVP / backward chains (conflict-free 16-B reads, mfma_layer<.., ROWS = true>) and the A / B
 // operand of the weight-gradient MFMAs (conflict-free 4-B reads).  76.8 KB per workgroup -> two per CU.
-template <int MODE, int N_IT, bool F16>
+template <int MODE, int N_IT>
 __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
   extern __shared__ f32x4 smem4[];
   const PiDims d = p.d;
@@ -345,10 +226,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
               *h2R4 = reinterpret_cast<const f32x4 *>(h2R), *u1R4 = reinterpret_cast<const f32x4 *>(u1R),
               *u2R4 = reinterpret_cast<const f32x4 *>(u2R), *wR4 = reinterpret_cast<const f32x4 *>(wR);
 
-  _Float16 *h1H = reinterpret_cast<_Float16 *>(h1R), *u1H = reinterpret_cast<_Float16 *>(u1R),
-           *u2H = reinterpret_cast<_Float16 *>(u2R);      // f16 path: h1, dh1 and delta2 as two-piece images
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // in an SGPR: every per-wave matrix pointer is scalar
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
   const int n_tiles = (p.n + BB - 1) / BB;
   constexpr int IMG4 = BB * HID / 4;    // float4s of one dense [32][128] activation image
@@ -361,24 +239,6 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
 #pragma unroll
   for (int t = 0; t < N_IT; ++t) zero(gW0[t]);
   zero(gW2);
-  // f16 path: this wave's n-tile of the three matrix images, and the A operand ring (filled with the tile's first matrix)
-  constexpr int RW = 4;
-  constexpr int NT16 = 8 * 2 * 64;
-  const u32x4 *wF1h = p.w.F1h + (size_t)wave * NT16, *wB1h = p.w.B1h + (size_t)wave * NT16, *vF1h = p.v.F1h + (size_t)wave * NT16;
-  const u32x4 *first_h = cached ? vF1h : wF1h;
-  WRing<F16 ? RW : 1> R;
-  __shared__ unsigned s_mx[4];    // largest |x|, |cotangent| of the tile (float bits)
-  float gbias1 = 0.0f;            // f16 path: d/d b1[32 wave + (lane & 31)], the samples split over the two lane halves
-  float bnd_x = 0.0f, bnd_0 = 0.0f, bnd_c = 0.0f;
-  if constexpr (F16) {
-    ring_fill(R, first_h, lane);
-    if (tid < 4) s_mx[tid] = 0u;
-    if constexpr (MODE == MODE_FVP) {
-      bnd_x = (float)d.D * p.v.mx[0];      // |dh1| <= max |x| D max |dW0| + max |db0|
-      bnd_0 = p.v.mx[1];
-    }
-    bnd_c = (float)d.A * p.w.mx[2];        // |delta2| <= max |cot| A max |W2|
-  }
   float gbias = 0.0f;   // thread n < 128: d/d b1[n]; thread 128 + n: d/d b0[n] (column sums of the delta images)
   float gb2p[4] = {0, 0, 0, 0}, glsp[4] = {0, 0, 0, 0};   // per (a = tid/32 + 8*it) partials over this thread's b
   double s_n = 0, s_ra = 0, s_rc = 0, s_kl = 0, s_cost = 0;
@@ -415,21 +275,9 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
     __syncthreads();
   }
 
-#ifdef CMBPO_STAMPS
-  unsigned long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long t_last = __builtin_amdgcn_s_memtime();
-  const unsigned long long t_rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int row0 = tile * BB;
-    // f16 path: the thread index is opaque per tile, or every per-lane address of the loop (48 slab addresses of the three
-    // matrix images, bias / batch pointers, ...) is hoisted out of it as a 64-bit VGPR pointer, and spilled
-    int tid_o = threadIdx.x;
-    if constexpr (F16) asm volatile("" : "+v"(tid_o));
-    const int tid = tid_o, lane = tid & 63, j = lane & 31, h = lane >> 5, lane_t = lane;
-    (void)j; (void)h;
     // ---- stage x in the row layout ---------------------------------------------------------------------
-    float xmax = 0.0f;
     if constexpr (PRE) {
 #pragma unroll
       for (int q = 0; q < 4 * N_IT; ++q) {
@@ -437,18 +285,14 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
         if (i < BB * d.D) {
           const int b = i / d.D, k = i - b * d.D;
           xR[b * XS + k] = xpre[q];
-          xmax = fmaxf(xmax, fabsf(xpre[q]));
         }
       }
     } else {
       for (int i = tid; i < BB * d.D; i += kThreads) {
         const int b = i / d.D, k = i - b * d.D;
-        const float xv = (row0 + b < p.n) ? p.obs[(size_t)row0 * d.D + i] : 0.0f;
-        xR[b * XS + k] = xv;
-        xmax = fmaxf(xmax, fabsf(xv));
+        xR[b * XS + k] = (row0 + b < p.n) ? p.obs[(size_t)row0 * d.D + i] : 0.0f;
       }
     }
-    if constexpr (F16 && MODE == MODE_FVP) thread_max_put(xmax, &s_mx[0], lane);   // (visible behind the next barrier)
     if constexpr (MODE == MODE_EVAL) {   // (the other modes fetch ahead later, next to their weight-gradient MFMAs)
       if (tile + (int)gridDim.x < n_tiles) fetch_x(tile + gridDim.x);
     }
@@ -485,15 +329,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int idx = tid + kThreads * i, b = idx >> 5, c = idx & 31;
-        if constexpr (F16) {
-          const float xv[4] = {t1[i][0], t1[i][1], t1[i][2], t1[i][3]};
-          unsigned q1[2], q2[2];
-          split4(xv, T_TANH, q1, q2);
-          *reinterpret_cast<uint2 *>(h1H + b * RSH + 4 * c) = make_uint2(q1[0], q1[1]);
-          *reinterpret_cast<uint2 *>(h1H + b * RSH + 4 * c + P2H) = make_uint2(q2[0], q2[1]);
-        } else {
-          reinterpret_cast<f32x4 *>(h1R)[b * (RS / 4) + c] = t1[i];
-        }
+        reinterpret_cast<f32x4 *>(h1R)[b * (RS / 4) + c] = t1[i];
         reinterpret_cast<f32x4 *>(h2R)[b * (RS / 4) + c] = t2[i];
       }
       __syncthreads();
@@ -506,37 +342,11 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
         f32x16 hv;
 #pragma unroll
         for (int r = 0; r < 16; ++r) hv[r] = cmbpo_fast_tanh(acc[0][0][r]);
-        if constexpr (F16) {
-          store_tile_H(hv, wave * 32, h1H, T_TANH, lane);
-          if constexpr (MODE == MODE_GRAD) {
-            // the fp32 h1 is saved from the registers (its LDS image holds the two pieces): a product that reads it back
-            // splits the same bits the same way
-            if (p.cache_w != nullptr) {
-              f32x4 *dst = p.cache_w + (size_t)tile * (2 * IMG4) + j * 32 + wave * 8 + h;
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                f32x4 xq;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xq[e] = hv[4 * q + e];
-                dst[2 * q] = xq;
-              }
-            }
-          }
-        } else {
-          store_tile_R(hv, wave * 32, h1R, RS, lane);
-        }
+        store_tile_R(hv, wave * 32, h1R, RS, lane);
       }
       __syncthreads();
-      if constexpr (F16) {
-        zero(acc[0][0]);
-        gemm_h<RW, true>(acc[0][0], R, wF1h, MODE == MODE_FVP ? vF1h : (MODE == MODE_GRAD ? wB1h : wF1h), h1H, lane, lane_t);
-        const f32x16 bb = load_bias(p.w.b1, wave * 32, lane), iv = load_bias(p.w.iF1, wave * 32, lane);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][0][r] = __builtin_fmaf(acc[0][0][r], iv[r] * T_TANH_INV, bb[r]);
-      } else {
-        acc[0][0] = load_bias(p.w.b1, wave * 32, lane);
-        mfma_layer<1, 1, true>(p.w.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, h1R4, lane, acc, RS);
-      }
+      acc[0][0] = load_bias(p.w.b1, wave * 32, lane);
+      mfma_layer<1, 1, true>(p.w.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, h1R4, lane, acc, RS);
       {
         f32x16 hv;
 #pragma unroll
@@ -550,60 +360,29 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int idx = tid + kThreads * i, b = idx >> 5, c = idx & 31;
-            if constexpr (!F16) dst[idx] = h1R4[b * (RS / 4) + c];
+            dst[idx] = h1R4[b * (RS / 4) + c];
             dst[IMG4 + idx] = h2R4[b * (RS / 4) + c];
           }
         }
       }
     }
 
-    PI_STAMP(0);
     if constexpr (MODE == MODE_FVP) {
       // ---- JVP chain: dh1 = (1-h1^2)(x dW0 + db0) ; dh2 = (1-h2^2)(dh1 W1 + h1 dW1 + db1) -----------
       acc[0][0] = load_bias(p.v.b0, wave * 32, lane);
       mfma_layer<1, 1, true>(p.v.F0 + (size_t)wave * d.kg0 * 64, 0, 0, d.kg0, xR4, lane, acc, XS);
-      float it1 = 1.0f;
-      if constexpr (F16) {
-        // (the barrier behind the staging made the tile's largest |x| visible)
-        const float t1 = pow2_lift(__builtin_fmaf(__uint_as_float(s_mx[0]), bnd_x, bnd_0));
-        it1 = pow2_inv(t1);
-        const f32x16 hh = load_tile_H(h1H, wave * 32, lane);
-        f32x16 o;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = __builtin_fmaf(-hh[r] * hh[r], T_TANH_INV * T_TANH_INV, 1.0f) * acc[0][0][r];
-        store_tile_H(o, wave * 32, u1H, t1, lane);
-      } else {
+      {
         const f32x16 hh = load_tile_R(h1R, RS, wave * 32, lane);
         f32x16 o;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] = (1.0f - hh[r] * hh[r]) * acc[0][0][r];
         store_tile_R(o, wave * 32, u1R, RS, lane);
       }
-      PI_STAMP(1);
       // the h1 dW1 half does not need dh1: it runs ahead of the barrier and absorbs the waves' skew
-      if constexpr (F16) {
-        f32x16 part;
-        zero(part);
-        gemm_h<RW, true>(part, R, vF1h, wF1h, h1H, lane, lane_t);
-        {
-          const f32x16 bb = load_bias(p.v.b1, wave * 32, lane), iv = load_bias(p.v.iF1, wave * 32, lane);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[0][0][r] = __builtin_fmaf(part[r], iv[r] * T_TANH_INV, bb[r]);
-        }
-        PI_STAMP(2);
-        __syncthreads();
-        PI_STAMP(3);
-        zero(part);
-        gemm_h<RW, true>(part, R, wF1h, wB1h, u1H, lane, lane_t);
-        const f32x16 iw = load_bias(p.w.iF1, wave * 32, lane);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][0][r] = __builtin_fmaf(part[r], iw[r] * it1, acc[0][0][r]);
-      } else {
-        acc[0][0] = load_bias(p.v.b1, wave * 32, lane);
-        mfma_layer<1, 1, true>(p.v.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, h1R4, lane, acc, RS);
-        __syncthreads();
-        mfma_layer<1, 1, true>(p.w.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, u1R4, lane, acc, RS);
-      }
+      acc[0][0] = load_bias(p.v.b1, wave * 32, lane);
+      mfma_layer<1, 1, true>(p.v.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, h1R4, lane, acc, RS);
+      __syncthreads();
+      mfma_layer<1, 1, true>(p.w.F1 + (size_t)wave * KGH * 64, 0, 0, KGH, u1R4, lane, acc, RS);
       {
         const f32x16 hh = load_tile_R(h2R, RS, wave * 32, lane);
         f32x16 o;
@@ -611,13 +390,10 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
         for (int r = 0; r < 16; ++r) o[r] = (1.0f - hh[r] * hh[r]) * acc[0][0][r];
         store_tile_R(o, wave * 32, u2R, RS, lane);
       }
-      PI_STAMP(4);
       // dmu = dh2 W2 + h2 dW2 (+ db2): K split over the 4 waves; the h2 dW2 half ahead of the barrier
       zero(acc[0][0]);
       mfma_layer<1, 1, true>(p.v.F2, 0, wave * 4, wave * 4 + 4, h2R4, lane, acc, RS);
-      PI_STAMP(5);
       __syncthreads();   // dh2 complete; every wave is done reading dh1 (u1R becomes the reduction image)
-      PI_STAMP(6);
       mfma_layer<1, 1, true>(p.w.F2, 0, wave * 4, wave * 4 + 4, u2R4, lane, acc, RS);
     } else {
       // mu = h2 W2 (+ b2): K split over the 4 waves
@@ -631,13 +407,11 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
     }
     __syncthreads();
 
-    PI_STAMP(7);
     // ---- element phase over (a, b): this thread owns b = tid & 31, a = tid/32 + 8*it ------------------
     const int eb = tid & 31, er = row0 + eb;
     const bool valid = er < p.n;
     float z_[4], mu_[4];
     float logp_part = 0.0f;
-    float cmax = 0.0f;      // f16 path: largest |cotangent| this thread writes
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int a = (tid >> 5) + 8 * it;
@@ -659,7 +433,6 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
           }
           wR[eb * 36 + a] = cot;
           gb2p[it] += cot;
-          cmax = fmaxf(cmax, fabsf(cot));
         } else {
           m += p.w.b2[a];
           mu_[it] = m;
@@ -708,56 +481,34 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
             const float cot = wgt * ratio * z_[it] * inv;                    // d logp / d mu = z / (sd + eps)
             wR[eb * 36 + a] = cot;
             gb2p[it] += cot;
-            cmax = fmaxf(cmax, fabsf(cot));
             glsp[it] += wgt * ratio * (z_[it] * z_[it] * sd * inv - 1.0f);  // d logp / d log_std
           }
         }
       }
     }
-    if constexpr (F16 && MODE != MODE_EVAL) thread_max_put(cmax, &s_mx[1], lane);
     __syncthreads();
-    PI_STAMP(8);
     if constexpr (MODE == MODE_EVAL) continue;
 
     // ---- backward: delta2 = (W2 cot) (1-h2^2) ; delta1 = (W1 delta2) (1-h1^2) --------------------------
     zero(acc[0][0]);
     mfma_layer<1, 1, true>(p.w.B2 + (size_t)wave * d.kga * 64, 0, 0, d.kga, wR4, lane, acc, 36);
-    float it2 = 1.0f;
     {
       const f32x16 hh = load_tile_R(h2R, RS, wave * 32, lane);
       f32x16 o;
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = (1.0f - hh[r] * hh[r]) * acc[0][0][r];
-      // dh2 is dead (the barrier after the reduction image)
-      if constexpr (F16) {
-        // (the barrier behind the element phase made the tile's largest |cotangent| visible)
-        const float t2 = pow2_lift(__uint_as_float(s_mx[1]) * bnd_c);
-        it2 = pow2_inv(t2);
-        store_tile_H(o, wave * 32, u2H, t2, lane);
-      } else {
-        store_tile_R(o, wave * 32, d2R, RS, lane);
-      }
+      store_tile_R(o, wave * 32, d2R, RS, lane);     // dh2 is dead (the barrier after the reduction image)
     }
     __syncthreads();
-    PI_STAMP(9);
     zero(acc[0][0]);
-    if constexpr (F16) {
-      gemm_h<RW, false>(acc[0][0], R, wB1h, nullptr, u2H, lane, lane_t);
-      const f32x16 iw = load_bias(p.w.iB1, wave * 32, lane), hh = load_tile_H(h1H, wave * 32, lane);
-      f32x16 o;
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        o[r] = __builtin_fmaf(-hh[r] * hh[r], T_TANH_INV * T_TANH_INV, 1.0f) * (acc[0][0][r] * (iw[r] * it2));
-      store_tile_R(o, wave * 32, d1R, RS, lane);     // the reduction image is dead (element phase barrier)
-    } else {
-      mfma_layer<1, 1, true>(p.w.B1 + (size_t)wave * KGH * 64, 0, 0, KGH, u2R4, lane, acc, RS);
+    mfma_layer<1, 1, true>(p.w.B1 + (size_t)wave * KGH * 64, 0, 0, KGH, u2R4, lane, acc, RS);
+    {
       const f32x16 hh = load_tile_R(h1R, RS, wave * 32, lane);
       f32x16 o;
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = (1.0f - hh[r] * hh[r]) * acc[0][0][r];
       store_tile_R(o, wave * 32, d1R, RS, lane);     // the reduction image is dead (element phase barrier)
     }
-    PI_STAMP(10);
     // ---- weight gradients: K = the tile's samples ---------------------------------------------------
     float warm = 0.0f;
     if constexpr (MODE != MODE_EVAL) {
@@ -771,16 +522,10 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
     }
     // dW1 and dW2 need delta2 / the cotangent only (complete since the previous barrier): they run while the slower
     // waves still write delta1
-    if constexpr (F16) {
-      wgrad_h(gW1, h1H, wave * 32, u2H, T_TANH_INV * it2, it2, wave, gbias1, lane);
-    } else {
 #pragma unroll
-      for (int J = 0; J < 4; ++J) wgrad_tile(gW1[J], h1R, RS, wave * 32, d2R, RS, J * 32, lane);
-    }
-    PI_STAMP(11);
+    for (int J = 0; J < 4; ++J) wgrad_tile(gW1[J], h1R, RS, wave * 32, d2R, RS, J * 32, lane);
     wgrad_tile(gW2, h2R, RS, wave * 32, wR, 36, 0, lane);
     __syncthreads();   // delta1 complete
-    PI_STAMP(12);
 #pragma unroll
     for (int t = 0; t < N_IT; ++t) wgrad_tile(gW0[t], xR, XS, 32 * t, d1R, RS, wave * 32, lane);
     {
@@ -788,26 +533,13 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
       const float *img = (tid < HID) ? d2R : d1R;
       const int n = tid & (HID - 1);
       float sb = 0.0f;
-      if (!F16 || tid >= HID) {     // (f16 path: the column sums of delta2 come out of its weight-gradient fragments)
 #pragma unroll 8
-        for (int b = 0; b < BB; ++b) sb += img[b * RS + n];
-      }
+      for (int b = 0; b < BB; ++b) sb += img[b * RS + n];
       gbias += sb;
-      if constexpr (F16) {
-        if (tid < 2) s_mx[tid] = 0u;     // every thread read them two barriers ago; the next tile's staging adds to them
-      }
     }
     asm volatile("" ::"v"(warm));   // the warm-up load must be issued, its value is not used
-    if constexpr (F16) ring_fill(R, first_h, lane_t);   // the next tile's first matrix: lands behind its staging
     __syncthreads();
-    PI_STAMP(13);
   }
-#ifdef CMBPO_STAMPS
-  if (p.stamps && threadIdx.x == 0) {
-    for (int k = 0; k < 14; ++k) p.stamps[(size_t)blockIdx.x * 16 + k] = t_acc[k];
-    p.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime() - t_rt0;
-  }
-#endif
 
   // ---- flush: this workgroup's partial vector (plain stores; reduce_parts_kernel adds the partials in a fixed order)
   if constexpr (MODE != MODE_EVAL) {
@@ -822,13 +554,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
         if (32 * t + row < d.D) part[d.oW0 + (32 * t + row) * HID + wave * 32 + j] = gW0[t][r];
       if (j < d.A) part[d.oW2 + (wave * 32 + row) * d.A + j] = gW2[r];
     }
-    if constexpr (F16) {
-      const float g1 = gbias1 + __shfl_xor(gbias1, 32, 64);
-      if (h == 0) part[d.ob1 + wave * 32 + j] = g1;
-      if (tid >= HID) part[d.ob0 + (tid & (HID - 1))] = gbias;
-    } else {
-      part[(tid < HID ? d.ob1 : d.ob0) + (tid & (HID - 1))] = gbias;
-    }
+    part[(tid < HID ? d.ob1 : d.ob0) + (tid & (HID - 1))] = gbias;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int a = (tid >> 5) + 8 * it;
@@ -858,6 +584,8 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
     }
   }
 }
+
+#include "pi_kernel_f16.h"
 
 // vec[i] = sum over workgroups of part[w][i], in workgroup order: the gradient / Fisher-vector product is bitwise
 // reproducible, and cheaper than 2 n_cu workgroups x P float atomics on the same P addresses (11 M atomics for the
@@ -1022,9 +750,10 @@ PiPack pack_ptrs(const cmbpo_pi *h, const float *base) {
   k.B2 = reinterpret_cast<const f32x4 *>(base + h->off_B2);
   k.b0 = base + h->off_b0; k.b1 = base + h->off_b1; k.b2 = base + h->off_b2; k.ls = base + h->off_ls;
   const u32x4 *b16 = h->blob16 + (base == h->blob ? 0 : H16_PACK);
-  k.F1h = b16; k.B1h = b16 + H16_MAT;
-  k.iF1 = reinterpret_cast<const float *>(b16 + 2 * H16_MAT); k.iB1 = k.iF1 + HID;
-  k.mx = k.iF1 + 2 * HID;
+  k.F0h = b16 + H16_F0; k.F1h = b16 + H16_F1; k.F2h = b16 + H16_F2; k.B1h = b16 + H16_B1; k.B2h = b16 + H16_B2;
+  const float *inv = reinterpret_cast<const float *>(b16 + H16_INV);
+  k.lift = inv + INV_LIFT;
+  k.mx = inv + INV_MX;
   return k;
 }
 
@@ -1059,26 +788,39 @@ int do_pack(const cmbpo_pi *h, float *dst, const float *flat, hipStream_t s) {
   add(h->off_ls, d.ols, d.A, 0, 0, 0, 0, 32);
   plan.total = total;
   plan.nb32 = cmbpo_ceil_div(total, 256);
-  plan.oW1 = d.oW1;
   plan.oW0 = d.oW0; plan.nW0 = d.D * HID; plan.ob0 = d.ob0; plan.oW2 = d.oW2; plan.nW2 = HID * d.A;
-  // the direction pack needs the forward image only (8 workgroups), the parameters both
+  // f16 images: the direction pack needs the forward ones only
   const bool params = dst == h->blob;
-  hipLaunchKernelGGL(pack_all_kernel, dim3(plan.nb32 + 1 + (params ? 16 : 8)), dim3(256), 0, s, dst, flat, plan,
+  const int s0 = 2 * d.n_it;
+  int ni = 0, blk = 0;
+  auto add16 = [&](int src_off, int sn, int sk, int n_lim, int k_lim, int n_tiles, int slabs, int dst_off, int lift_idx) {
+    plan.img[ni] = H16Img{src_off, sn, sk, n_lim, k_lim, n_tiles, slabs, dst_off, lift_idx};
+    plan.img_blk[ni++] = blk;
+    blk += cmbpo_ceil_div(n_tiles * slabs * 64, 256);
+  };
+  add16(d.oW0, 1, HID, HID, d.D, 4, s0, H16_F0, L_F0);          // A[unit][input] = W0[input][unit]
+  add16(d.oW1, 1, HID, HID, HID, 4, 8, H16_F1, L_F1);           // A[unit][k] = W1[k][unit]
+  add16(d.oW2, 1, d.A, d.A, HID, 1, 8, H16_F2, L_F2);           // A[action][k] = W2[k][action]
+  if (params) {
+    add16(d.oW1, HID, 1, HID, HID, 4, 8, H16_B1, L_B1);         // A[unit][k] = W1[unit][k]
+    add16(d.oW2, d.A, 1, HID, d.A, 4, 2, H16_B2, L_B2);         // A[unit][action] = W2[unit][action]
+  }
+  plan.img_blk[ni] = blk;
+  plan.n_img = ni;
+  hipLaunchKernelGGL(pack_all_kernel, dim3(plan.nb32 + 1 + blk), dim3(256), 0, s, dst, flat, plan,
                      h->blob16 + (params ? 0 : H16_PACK));
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }
 
-size_t lds_bytes(const PiDims &d) {
-  const size_t f = (size_t)BB * (d.in_pad + 4) + 4 * BB * RS + BB * 36;
+size_t lds_bytes(const PiDims &d, bool f16) {
+  const size_t f = (size_t)BB * ((f16 ? 32 * d.n_it : d.in_pad) + 4) + 4 * BB * RS + BB * 36;
   return f * sizeof(float);
 }
 
-template <int MODE, int N_IT, bool F16>
-int launch_pi_n(cmbpo_pi *h, PiArgs &a, hipStream_t s) {
-  auto kern = pi_kernel<MODE, N_IT, F16>;
-  static size_t attr_bytes = 0;   // the kernel also has a few bytes of static LDS: ask for what is needed
-  const size_t lds = lds_bytes(h->d);
+template <class KERN>
+int launch_pi_k(cmbpo_pi *h, PiArgs &a, hipStream_t s, KERN kern, size_t &attr_bytes, bool f16, bool reduce) {
+  const size_t lds = lds_bytes(h->d, f16);   // (the kernels also have a few bytes of static LDS: ask for what is needed)
   if (lds > attr_bytes) {
     CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1090,17 +832,25 @@ int launch_pi_n(cmbpo_pi *h, PiArgs &a, hipStream_t s) {
   a.part = h->parts; a.part_ld = h->part_ld;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, s, a);
   h->last_grid = grid;
-  if (MODE != MODE_EVAL && a.vec != nullptr)
+  if (reduce && a.vec != nullptr)
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(cmbpo_ceil_div(h->d.P, 64)), dim3(1024), 0, s, h->parts, h->part_ld, grid,
                        h->d.P, a.vec);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }
 
+template <int MODE, int N_IT>
+int launch_pi_n(cmbpo_pi *h, PiArgs &a, hipStream_t s) {
+  static size_t attr[3] = {0, 0, 0};   // per kernel: the dynamic LDS already granted
+  if (pi_path() == 0) return launch_pi_k(h, a, s, pi_kernel<MODE, N_IT>, attr[0], false, MODE != MODE_EVAL);
+  if (MODE == MODE_FVP && a.cache_r != nullptr)
+    return launch_pi_k(h, a, s, pi_kernel_h<MODE, N_IT, true>, attr[1], true, MODE != MODE_EVAL);
+  return launch_pi_k(h, a, s, pi_kernel_h<MODE, N_IT, false>, attr[2], true, MODE != MODE_EVAL);
+}
+
 template <int MODE>
 int launch_pi(cmbpo_pi *h, PiArgs &a, hipStream_t s) {
-  if (pi_path() == 0) return h->d.n_it > 1 ? launch_pi_n<MODE, 2, false>(h, a, s) : launch_pi_n<MODE, 1, false>(h, a, s);
-  return h->d.n_it > 1 ? launch_pi_n<MODE, 2, true>(h, a, s) : launch_pi_n<MODE, 1, true>(h, a, s);
+  return h->d.n_it > 1 ? launch_pi_n<MODE, 2>(h, a, s) : launch_pi_n<MODE, 1>(h, a, s);
 }
 
 int fill_args(cmbpo_pi *h, const cmbpo_pi_batch_t *b, PiArgs &a, const char *who) {

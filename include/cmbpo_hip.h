@@ -369,11 +369,11 @@ int cmbpo_pi_keep_activations(cmbpo_pi_t *h, int enable);
  * captured into the CG graph counts once); diagnostics / tests. */
 long cmbpo_pi_saved_activation_uses(const cmbpo_pi_t *h);
 
-/* Arithmetic of the 128 x 128 products of the policy kernels (h1 W1, h1 dW1,
- * dh1 W1, delta2 W1^T and the W1 weight gradient): 1 (default) = three f16 MFMAs
- * on two-piece operands (11 + 1 + 11 mantissa bits, fp32 accumulation: the error
- * of a product stays at fp32's), 0 = fp32 MFMAs throughout.
- * Environment CMBPO_PI_F16=0 selects 0 at load. */
+/* Arithmetic of the policy kernels' matrix products (forward, JVP, backward and
+ * weight-gradient): 1 (default) = three f16 MFMAs on two-piece operands (11 + 1 +
+ * 11 mantissa bits, fp32 accumulation: the error of a product stays at fp32's,
+ * see DESIGN.md 3a), 0 = fp32 MFMAs throughout (round 1).  Environment
+ * CMBPO_PI_F16=0 selects 0 at load. */
 void cmbpo_set_pi_matrix_path(int path);
 int cmbpo_get_pi_matrix_path(void);
 

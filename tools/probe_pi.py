@@ -38,7 +38,8 @@ for path in (0, 1):
             e1.record(); torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps
         print(f"path {path} keep {int(keep)} N={N} D={D} A={A}: loss_grad {timeit(lambda: ops.loss_grad(0)):.3f} ms  "
-              f"fvp {timeit(lambda: ops.fvp(v)):.3f} ms  eval {timeit(ops.evals):.3f} ms", flush=True)
+              f"fvp {timeit(lambda: ops.fvp(v)):.3f} ms (x5) {timeit(lambda: ops.fvp(v), 40):.3f} ms (x40)  "
+              f"eval {timeit(ops.evals):.3f} ms", flush=True)
         del ops
 for keep in (False, True):
     for i, name in enumerate(("grad", "fvp", "sums")):

@@ -167,7 +167,7 @@ def rollout_phase(sampler, pool, start, max_samples=None):
     """reset -> sample until everything is finished -> finish_all_paths -> get(); returns samples."""
     sampler.reset(start)
     while sampler.any_alive() and pool.has_room:
-        sampler.sample(max_samples=max_samples)
+        sampler.sample_many(max_samples=max_samples)     # the loop over sample() in native code (same steps, same results)
     diag = sampler.finish_all_paths()
     res, bdiag = pool.get(as_tensors=True)
     return int(diag["msampler/samples_added"]), res

@@ -92,6 +92,8 @@ SIGNATURES.update({
     "cmbpo_rollout_read_scalars": (_i, [_rp, _p, _p]),
     "cmbpo_rollout_compact": (_i, [_rp, _p]),
     "cmbpo_rollout_step": (_i, [_rp, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
+    "cmbpo_rollout_run": (_i, [_rp, _i, _p, _p, _p, _p, _i, _i, _p, _p, C.c_long, C.c_long, _p, _p, _i, C.c_double, _i, _p,
+                               C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _p]),
     "cmbpo_buffer_offsets": (_i, [_rp, _p, _p]),
     "cmbpo_buffer_moments": (_i, [_rp, _i, _p, _p]),
     "cmbpo_buffer_flatten": (_i, [_rp, _p, _p, C.POINTER(C.c_void_p), _p]),

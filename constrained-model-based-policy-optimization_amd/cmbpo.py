@@ -222,13 +222,13 @@ class CMBPO:
                     btz_b = self._buffer.distributed_batch_from_archive(self._rollout_batch_size, btz_dist,
                                                                         fields=['observations', 'pi_infos'])
                     self.model_sampler.reset(btz_b['observations'])
-                    for i in count():
-                        _, _, _, info = self.model_sampler.sample(max_samples=int(self.approx_model_batch - samples_added))
-                        if self.model_sampler._total_samples + samples_added >= .99 * self.approx_model_batch:
-                            keep_rolling = False
-                            break
-                        if info['alive_ratio'] <= 0.1:
-                            break
+                    # the reference's loop over sample() (:352-360: stop at 99 % of the batch or at alive_ratio <= 0.1),
+                    # taken in native code
+                    self.model_sampler.sample_many(max_samples=int(self.approx_model_batch - samples_added),
+                                                   stop_total=.99 * self.approx_model_batch - samples_added,
+                                                   min_alive_ratio=0.1)
+                    if self.model_sampler._total_samples + samples_added >= .99 * self.approx_model_batch:
+                        keep_rolling = False
                     rollout_diagnostics = self.model_sampler.finish_all_paths()
                     model_samples_new, buffer_diagnostics_new = self.model_buf.get(as_tensors=True)
                     model_samples = [torch.cat((o, n), dim=0) for o, n in zip(model_samples, model_samples_new)] \

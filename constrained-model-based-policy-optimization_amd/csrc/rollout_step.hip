@@ -43,3 +43,52 @@ extern "C" int cmbpo_rollout_step(const cmbpo_rollout_t *r, int n_alive, cmbpo_m
   }
   return cmbpo_rollout_finish(r, 1, stream);
 }
+
+// Several steps in one call: what ModelSampler.sample()'s caller does between two steps (read the step's counters, swap the
+// alive lists and the cur / next arrays, advance the column) without leaving native code -- at 1e3 branches a step is
+// ~85 us of kernels and the interpreter between two steps was a quarter of it.  *r is updated in place exactly as the
+// per-step caller would leave it.  Stops after max_steps, when no branch is alive, when at most min_alive are (the
+// reference's `alive_ratio <= 0.1`, algorithms/cmbpo.py:358-359), when total_samples reaches stop_total (>= 0; :356-357)
+// or when the buffer is full.  d_eps / d_elite: the draws of the first step, one step further every eps_stride /
+// elite_stride elements.  h_scalars: [max_steps][384 B] (pinned), the counters of every step taken.
+extern "C" int cmbpo_rollout_run(cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy, cmbpo_mlp_t *model, cmbpo_mlp_t *v,
+                                 cmbpo_mlp_t *vc, int task, int ensemble, const float *d_eps, const int32_t *d_elite,
+                                 long eps_stride, long elite_stride, float *d_mean, float *d_var, int max_steps,
+                                 double stop_total, int min_alive, void *h_scalars, int *steps_done, int *n_alive_out,
+                                 int *list_swaps, void *stream) {
+  CMBPO_REQUIRE(r && h_scalars && steps_done && n_alive_out && list_swaps, "cmbpo_rollout_run: NULL argument");
+  CMBPO_REQUIRE(max_steps >= 1, "cmbpo_rollout_run: max_steps %d", max_steps);
+  CMBPO_REQUIRE(!r->use_host_budget, "cmbpo_rollout_run: the cross-shard budget exchange needs the per-step path");
+  int done = 0, swaps = 0;
+  while (done < max_steps && n_alive > 0 && r->ptr < r->T) {
+    int rc = cmbpo_rollout_step(r, n_alive, policy, model, v, vc, task, ensemble, d_eps + (size_t)done * eps_stride,
+                                d_elite + (size_t)done * elite_stride, d_mean, d_var, stream);
+    if (rc != 0 && rc != 1) return rc;
+    char *h = static_cast<char *>(h_scalars) + (size_t)done * 384;
+    if (int rc2 = cmbpo_rollout_read_scalars(r, h, stream)) return rc2;     // the host sync of the step
+    const int32_t *isc = reinterpret_cast<const int32_t *>(h);
+    const double *dsc = reinterpret_cast<const double *>(h + 128);
+    const int fin = isc[CMBPO_I_N_FIN_PRE] + isc[CMBPO_I_N_FIN_POST];
+    bool swap_lists = rc == 1;
+    if (rc == 0 && fin > 0) {
+      if (int rc2 = cmbpo_rollout_compact(r, stream)) return rc2;           // the alive list only changes when a branch finished
+      swap_lists = true;
+    }
+    if (swap_lists) {
+      int32_t *t = r->alive_idx; r->alive_idx = r->alive_idx_out; r->alive_idx_out = t;
+      ++swaps;
+    }
+    n_alive -= fin;
+    { const float *t = r->cur_obs; r->cur_obs = r->next_obs; r->next_obs = t; }
+    { const float *t = r->v_t; r->v_t = r->v_n; r->v_n = t; }
+    { const float *t = r->vc_t; r->vc_t = r->vc_n; r->vc_n = t; }
+    r->ptr += 1;
+    ++done;
+    if (n_alive <= min_alive) break;
+    if (stop_total >= 0.0 && dsc[CMBPO_D_TOTAL_SAMPLES] >= stop_total) break;
+  }
+  *steps_done = done;
+  *n_alive_out = n_alive;
+  *list_swaps = swaps;
+  return CMBPO_OK;
+}

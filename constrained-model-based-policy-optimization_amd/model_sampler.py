@@ -281,7 +281,8 @@ class ModelSampler:
         at small rollout batches a step is a chain of launch latencies).  Returns the chunk list
         [next step, eps [K, B, A], elite indices [K, B]]."""
         B, A = self.batch_size, self.pool.act_dim
-        K = max(1, min(8, int(2 ** 28 // max(B * A * 4, 1))))
+        step_bytes = max(B * A * 4, 1)
+        K = max(1, min(40, max(2 ** 23 // step_bytes, min(8, 2 ** 28 // step_bytes))))    # a whole rollout at small batches
         e_ck = torch.randn((K, B, A), generator=self._gen, dtype=torch.float32, device=self.device)
         d_ck = torch.randint(0, len(self._elites), (K, B), generator=self._gen, device=self.device)
         self._draws = [0, e_ck, self._elites[d_ck]]
@@ -337,6 +338,87 @@ class ModelSampler:
         self._host["total_dkl"] = float(dsc[_lib.D_TOTAL_DKL])
         info = {"alive_ratio": pool.n_alive / self.batch_size, "ensemble_dkl_path": t["dkl_t"], "cost": t["cost_t"]}
         return t["cur_obs"], t["rew_t"], t["term_t"], info
+
+    def sample_many(self, max_steps=None, max_samples=None, stop_total=None, min_alive_ratio=None):
+        """Consecutive sample() calls without the interpreter between them (cmbpo_rollout_run): the rollout loop of
+        algorithms/cmbpo.py:352-360.  Steps until `max_steps` are taken, no branch is alive, the buffer is full,
+        alive / batch_size <= min_alive_ratio (:358-359) or the sampler's total_samples >= stop_total (:356-357) -- each
+        test made after a step, as the reference's loop makes them.  `max_samples` is the budget every step is given.
+        Returns (steps taken, info of the last step).  On a sharded sampler, with injected draws or with kernel events
+        on, the same loop runs over sample()."""
+        pool, env, pol = self.pool, self.env, self.policy
+        sharded = self.comm is not None and self.comm.world > 1
+        min_alive = int(np.floor(min_alive_ratio * self.batch_size + 1e-9)) if min_alive_ratio is not None else 0
+        left = int(max_steps) if max_steps is not None else (1 << 30)
+        steps, info = 0, None
+        if sharded or env.kernel_events is not None:
+            while left > 0 and self.any_alive() and pool.has_room:
+                _, _, _, info = self.sample(max_samples=max_samples)
+                steps += 1
+                left -= 1
+                if stop_total is not None and self._total_samples >= stop_total:
+                    break
+                if min_alive_ratio is not None and info["alive_ratio"] <= min_alive_ratio:
+                    break
+            return steps, info
+        t, rs = pool.t, pool.rs
+        B, A = self.batch_size, pool.act_dim
+        lib = _lib.lib()
+        with torch.cuda.device(self.device):
+            if getattr(self, "_scratch", None) is None or self._scratch[0].shape[1] != B:
+                E, O = env._model.num_nets, env.output_dim
+                self._scratch = (torch.empty((E, B, O), dtype=torch.float32, device=self.device),
+                                 torch.empty((E, B, O), dtype=torch.float32, device=self.device))
+                self._handles = None
+            if getattr(self, "_handles", None) is None:
+                self._handles = (pol.actor.mlp.handle, env._model.mlp.handle, pol.v.mlp.handle, pol.vc.mlp.handle,
+                                 self._scratch[0].data_ptr(), self._scratch[1].data_ptr())
+            h = self._handles
+            if getattr(self, "_run_host", None) is None:
+                self._run_host = torch.empty((64, 384), dtype=torch.uint8, pin_memory=True)
+                self._run_out = (C.c_int(0), C.c_int(0), C.c_int(0))
+            rs.max_samples = int(max_samples) if max_samples else 0
+            rs.dkl_lim = float(self.dkl_lim)
+            rs.max_path_length = self._max_path_length
+            rs.use_host_budget = 0
+            stream = _lib.current_stream()
+            stop = -1.0 if stop_total is None else float(stop_total)
+            done_o, alive_o, swaps_o = self._run_out
+            while left > 0 and pool.n_alive > 0 and pool.has_room:
+                ck = self._draws
+                if ck is None or ck[0] >= ck[1].shape[0] or ck[1].shape[1] != B:
+                    ck = self._draw_chunk()
+                k = ck[0]
+                take = min(left, ck[1].shape[0] - k, 64)
+                _lib.check(lib.cmbpo_rollout_run(
+                    C.byref(rs), pool.n_alive, h[0], h[1], h[2], h[3], env._task_id, env._model.num_nets,
+                    ck[1].data_ptr() + k * B * A * 4, ck[2].data_ptr() + k * B * ck[2].element_size(), B * A, B,
+                    h[4], h[5], take, stop, min_alive, self._run_host.data_ptr(), C.byref(done_o), C.byref(alive_o),
+                    C.byref(swaps_o), stream), "cmbpo_rollout_run")
+                done = done_o.value
+                if done == 0:
+                    break
+                # the struct was advanced in native code: bring the tensor table to the same state
+                if done & 1:
+                    for a, b in (("cur_obs", "next_obs"), ("v_t", "v_n"), ("vc_t", "vc_n")):
+                        t[a], t[b] = t[b], t[a]
+                if swaps_o.value & 1:
+                    t["alive_idx"], t["alive_idx_out"] = t["alive_idx_out"], t["alive_idx"]
+                ck[0] = k + done
+                pool.ptr += done
+                self._n_episodes += done
+                steps += done
+                left -= done
+                last = self._run_host[done - 1]
+                isc, dsc = last[:128].view(torch.int32).numpy().copy(), last[128:].view(torch.float64).numpy().copy()
+                pool._n_alive, pool._size = alive_o.value, int(isc[_lib.I_SIZE])
+                self._dsc = dsc
+                self._host["total_samples"] = float(dsc[_lib.D_TOTAL_SAMPLES])
+                self._host["total_dkl"] = float(dsc[_lib.D_TOTAL_DKL])
+                info = {"alive_ratio": pool.n_alive / B, "ensemble_dkl_path": t["dkl_t"], "cost": t["cost_t"]}
+                if done < take:       # a stop test fired inside the call
+                    break
+        return steps, info
 
     def _idle_step(self, max_samples):
         pool, t = self.pool, self.pool.t

@@ -296,6 +296,19 @@ int cmbpo_rollout_step(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *polic
                        cmbpo_mlp_t *v, cmbpo_mlp_t *vc, int task, int ensemble, const float *d_eps,
                        const int32_t *d_elite, float *d_mean, float *d_var, void *stream);
 
+/* Several steps in one call (single-rank path; replaces the body of the rollout loop of algorithms/cmbpo.py:352-360
+ * around ModelSampler.sample): step -> counters -> swap of the alive lists and of the cur / next arrays, repeated
+ * until max_steps, no branch alive, at most min_alive alive (`alive_ratio <= 0.1`), total_samples >= stop_total
+ * (stop_total < 0: no such test) or a full buffer.  *r is left as the caller of cmbpo_rollout_step would leave it.
+ * d_eps / d_elite: the draws of the first step; step k reads them k * eps_stride / k * elite_stride elements on.
+ * h_scalars: [max_steps][384 bytes] of host memory (pinned), the counters of every step taken (iscal | dscal);
+ * *list_swaps = how often alive_idx / alive_idx_out changed places. */
+int cmbpo_rollout_run(cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy, cmbpo_mlp_t *model, cmbpo_mlp_t *v,
+                      cmbpo_mlp_t *vc, int task, int ensemble, const float *d_eps, const int32_t *d_elite,
+                      long eps_stride, long elite_stride, float *d_mean, float *d_var, int max_steps,
+                      double stop_total, int min_alive, void *h_scalars, int *steps_done, int *n_alive_out,
+                      int *list_swaps, void *stream);
+
 /* ModelBuffer.get (modelbuffer.py:184-226): d_offsets[B+1] = exclusive scan of
  * len; d_stats[8] = {n, adv_mean, adv_std, cadv_mean, ret_mean, cret_mean}
  * (two-pass mean / std of utilities/mpi_tools.py:71-92).  With d_gstats

@@ -100,6 +100,33 @@ def test_fvp_is_linear_and_symmetric(hip_lib):
     assert np.dot(v, hv) >= 0 and np.dot(u, hu) >= 0
 
 
+def test_fvp_power_of_two_scaling_is_exact_and_zero_stays_zero(hip_lib):
+    """Every lift of the f16 path is a power of two derived from the operand it lifts: a direction scaled by 2^k gives the
+    same pieces under a lift scaled by 2^-k, so the product scales bit for bit (as it does for fp32 MFMAs); a zero
+    direction takes the lift-of-zero branches and returns exact zeros."""
+    _need_gpu()
+    rng, params, batch, graph, ops = _setup(29, 8, 777, seed=5)
+    ops.loss_grad(0)      # saves the activations: the products below run on the saved-activation kernel
+    v = rng.standard_normal(params.shape).astype(np.float32)
+    hv = ops.fvp(v)
+    for k in (-30, 20):
+        a = np.float32(2.0 ** k)
+        np.testing.assert_array_equal(ops.fvp(v * a), hv * a, err_msg=f"2^{k}")
+    np.testing.assert_array_equal(ops.fvp(np.zeros_like(v)), np.zeros_like(v))
+
+
+def test_fvp_wide_range_direction_agrees_between_the_matrix_paths(hip_lib, pi_path):
+    """One lift per matrix: rows of a direction 1e7 apart in magnitude still come out at fp32 accuracy where it matters
+    (errors measured against the largest component, as for every gradient-like vector here)."""
+    _need_gpu()
+    rng, params, batch, graph, ops = _setup(29, 8, 500, seed=6)
+    v = rng.standard_normal(params.shape).astype(np.float32)
+    scale = (10.0 ** rng.uniform(-4, 3, size=params.shape)).astype(np.float32)
+    v = v * scale
+    got = ops.fvp(v) + np.float32(0.1) * v
+    _close(got, graph.fisher_vp(params, v, 0.1), msg="wide-range direction")
+
+
 SCENARIOS = [   # name, cost_p, cadv_scale, cost_lim, constrained, real_cost, seed
     ("feasible", 0.05, 1.0, 10.0, True, 3.0, 11),
     ("violating", 0.9, 1.0, 10.0, True, 25.0, 12),

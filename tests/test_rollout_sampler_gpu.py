@@ -162,6 +162,54 @@ def test_hip_sampler_matches_oracle_on_fresh_seeds(hip_lib, task, B, T, hidden, 
             np.testing.assert_allclose(arr, r, rtol=TOL[k], atol=TOL[k], err_msg=k)
 
 
+@pytest.mark.parametrize("task,B,T,mode,lim_scale,budget,stop_frac,min_ratio", [
+    ("AntSafe-v2", 1000, 12, "uncertainty", 2.5, 9000, None, None),     # small-batch path (one-workgroup bookkeeping), budget
+    ("AntSafe-v2", 1000, 12, "schedule", None, None, 0.5, 0.1),         # stop on total_samples / alive ratio (cmbpo.py:356-359)
+    ("HalfCheetahSafe-v2", 6000, 7, "uncertainty", 2.5, None, None, 0.1),  # > 4096 rows: separate bookkeeping calls + compaction
+])
+def test_sample_many_equals_a_loop_of_sample(hip_lib, task, B, T, mode, lim_scale, budget, stop_frac, min_ratio):
+    """cmbpo_rollout_run (ModelSampler.sample_many) takes exactly the steps a Python loop of sample() takes: same
+    stopping step, bit-identical buffers."""
+    _need_gpu()
+    from worlds import build_world
+    from cmbpo_amd import synthetic
+    w = build_world(77, task, 128, q_boost=1.2 if task == "AntSafe-v2" else 0.0)
+    start = synthetic.start_states(np.random.default_rng(78), B, task)
+    stop_total = None if stop_frac is None else stop_frac * B * T
+    out = []
+    for many in (False, True):
+        sampler, pool = hip_world(w, task, T, mode, float("inf"), B, 128)
+        if lim_scale is not None:
+            # a limit some branches exceed: calibrate on one step of a throw-away sampler with the same seeds
+            cal, _ = hip_world(w, task, T, mode, float("inf"), B, 128)
+            cal._gen.manual_seed(5)
+            cal.reset(start)
+            _, _, _, info = cal.sample()
+            sampler.set_rollout_dkl(lim_scale * float(np.median(info["ensemble_dkl_path"].cpu().numpy()[:B])))
+        sampler._gen.manual_seed(5)
+        sampler.reset(start)
+        steps = 0
+        if many:
+            steps, info = sampler.sample_many(max_samples=budget, stop_total=stop_total, min_alive_ratio=min_ratio)
+        else:
+            while sampler.any_alive() and pool.has_room:
+                _, _, _, info = sampler.sample(max_samples=budget)
+                steps += 1
+                if stop_total is not None and sampler._total_samples >= stop_total:
+                    break
+                if min_ratio is not None and info["alive_ratio"] <= min_ratio:
+                    break
+        state = (steps, pool.n_alive, pool.ptr, sampler._total_samples, info["alive_ratio"])
+        diag = sampler.finish_all_paths()
+        res, _ = pool.get()
+        out.append((state, diag["msampler/samples_added"], res))
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    assert out[0][0][0] >= 2
+    assert out[0][1] == out[1][1]
+    for k, a, b in zip(NAMES, out[0][2], out[1][2]):
+        np.testing.assert_array_equal(a, b, err_msg=k)
+
+
 def test_modelbuffer_api_parity_with_host_arrays(hip_lib):
     """store_multiple / finish_path_multiple / get driven with host arrays (the reference's call
     pattern) against the oracle's GAE on ragged finish patterns: finish at ptr = 0, mid-way, and at

@@ -120,20 +120,22 @@ struct PackPlan {
 
 __device__ __forceinline__ void pack_f16_part(u32x4 *dst16, const float *flat, const H16Img &im, int blk) {
   // every workgroup of an image first finds the matrix's largest magnitude (16 K elements from L2: cheaper than a launch)
-  __shared__ float red[256];
+  // (the matrix is one contiguous run of the flat vector whichever way the image walks it, and a maximum has no order)
+  __shared__ float red[4];
   const float *src = flat + im.src_off;
+  const int n4 = im.n_lim * im.k_lim / 4;     // (every matrix of the policy is a multiple of 128 floats, 16-byte aligned)
+  const f32x4 *src4 = reinterpret_cast<const f32x4 *>(src);
   float mx = 0.0f;
-  for (int e = threadIdx.x; e < im.n_lim * im.k_lim; e += 256) {
-    const int n = e / im.k_lim, k = e - n * im.k_lim;
-    mx = fmaxf(mx, fabsf(src[(size_t)n * im.sn + (size_t)k * im.sk]));
+#pragma unroll 16                             // all of a thread's loads in flight at once (<= 16 for 128 x 128)
+  for (int e = threadIdx.x; e < n4; e += 256) {
+    const f32x4 q = src4[e];
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(q[0]), fabsf(q[1]))), fmaxf(fabsf(q[2]), fabsf(q[3])));
   }
-  red[threadIdx.x] = mx;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
-    __syncthreads();
-  }
-  const float S = pow2_lift(red[0]);
+  const float S = pow2_lift(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
   if (blk == 0 && threadIdx.x == 0) {
     float *lift = reinterpret_cast<float *>(dst16 + H16_INV) + INV_LIFT;
     lift[im.lift_idx] = S;
@@ -769,6 +771,7 @@ int pi_path() {
 
 int do_pack(const cmbpo_pi *h, float *dst, const float *flat, hipStream_t s) {
   const PiDims &d = h->d;
+  CMBPO_REQUIRE((reinterpret_cast<uintptr_t>(flat) & 15u) == 0, "policy pack: the flat vector must be 16-byte aligned");
   PackPlan plan;
   int q = 0, total = 0;
   auto add = [&](size_t off, int src_off, int n_lim, int k_lim, int sn, int sk, int kg, int count) {

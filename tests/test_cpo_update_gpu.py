@@ -54,7 +54,7 @@ def _setup(D, A, n, seed, cost_p=0.3, cadv_scale=1.0, T=35):
     return rng, params, batch, graph, ops
 
 
-@pytest.mark.parametrize("D,A,n", [(29, 8, 1037), (20, 6, 64), (47, 17, 500), (21, 3, 31)])
+@pytest.mark.parametrize("D,A,n", [(29, 8, 1037), (20, 6, 64), (47, 17, 500), (21, 3, 31), (64, 32, 257), (3, 1, 100)])
 def test_loss_grad_fvp_eval_match_oracle(hip_lib, D, A, n):
     _need_gpu()
     rng, params, batch, graph, ops = _setup(D, A, n, seed=D * 100 + A)

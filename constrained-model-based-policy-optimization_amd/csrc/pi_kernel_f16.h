@@ -82,9 +82,12 @@ __device__ __forceinline__ f32x16 load_tile_H(const _Float16 *img, int n_base, i
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const _Float16 *src = img + j * RSH + n_base + 8 * q + 4 * h;
-    const f16x4 a = *reinterpret_cast<const f16x4 *>(src), b = *reinterpret_cast<const f16x4 *>(src + P2H);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[4 * q + e] = (float)a[e] + (float)b[e];
+    const uint2 a = *reinterpret_cast<const uint2 *>(src), b = *reinterpret_cast<const uint2 *>(src + P2H);
+    // p1 + p2 as one mixed-precision FMA per value (p1 x 1.0 + p2, both f16 sources, fp32 result)
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(v[4 * q]) : "v"(a.x), "v"(b.x));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(v[4 * q + 1]) : "v"(a.x), "v"(b.x));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(v[4 * q + 2]) : "v"(a.y), "v"(b.y));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(v[4 * q + 3]) : "v"(a.y), "v"(b.y));
   }
   return v;
 }
@@ -374,6 +377,20 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
     __syncthreads();
   }
 
+  // saved activations: a tile's two images travel L2 -> registers while the previous tile ends (they were pulled from HBM
+  // into L2 by the warm-up touch a phase earlier); requested any sooner, the 32 registers spill across the weight gradients
+  // (h1 only: with h2's 16 registers as well, the end of the tile spills; and only the one-row-tile input layer has
+  // those 16 to spare)
+  constexpr bool ACT_PRE = !FWD && N_IT == 1;
+  f32x4 act1[4];
+  auto fetch_act = [&](int t, int tid) {
+    const f32x4 *src = p.cache_r + (size_t)t * (2 * IMG4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) act1[i] = src[tid + kThreads * i];
+  };
+  if constexpr (ACT_PRE) {
+    if ((int)blockIdx.x < n_tiles) fetch_act(blockIdx.x, tid0);
+  }
 #ifdef CMBPO_STAMPS
   unsigned long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = __builtin_amdgcn_s_memtime();
@@ -435,22 +452,26 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
     if constexpr (!FWD) {
       // ---- h1, h2 as cmbpo_pi_loss_grad left them (same parameters, same batch): h1 is split the way the forward pass
       // splits it, so the products see identical bits
-      const f32x4 *src = p.cache_r + (size_t)tile * (2 * IMG4);
-      f32x4 t1[4], t2[4];
+      // (h1 was requested at the end of the previous tile, behind its last weight gradient)
+      f32x4 act2[4];
+      {
+        const f32x4 *src = p.cache_r + (size_t)tile * (2 * IMG4);
+        if constexpr (!ACT_PRE) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        t1[i] = src[tid + kThreads * i];
-        t2[i] = src[IMG4 + tid + kThreads * i];
+          for (int i = 0; i < 4; ++i) act1[i] = src[tid + kThreads * i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) act2[i] = src[IMG4 + tid + kThreads * i];
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int idx = tid + kThreads * i, b = idx >> 5, c = idx & 31;
         unsigned q1[2], q2[2];
-        split2<false>(t1[i][0], t1[i][1], T_TANH, q1[0], q2[0]);
-        split2<false>(t1[i][2], t1[i][3], T_TANH, q1[1], q2[1]);
+        split2<false>(act1[i][0], act1[i][1], T_TANH, q1[0], q2[0]);
+        split2<false>(act1[i][2], act1[i][3], T_TANH, q1[1], q2[1]);
         *reinterpret_cast<uint2 *>(h1H + b * RSH + 4 * c) = make_uint2(q1[0], q1[1]);
         *reinterpret_cast<uint2 *>(h1H + b * RSH + 4 * c + P2H) = make_uint2(q2[0], q2[1]);
-        reinterpret_cast<f32x4 *>(h2R)[b * (RS / 4) + c] = t2[i];
+        reinterpret_cast<f32x4 *>(h2R)[b * (RS / 4) + c] = act2[i];
       }
       __syncthreads();
       t_x = pow2_lift(__uint_as_float(mx[0]));
@@ -726,6 +747,10 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
     }
     asm volatile("" ::"v"(warm));   // the warm-up load must be issued, its value is not used
     ring_fill<ST>(R, imgs, lane);   // the next tile's first slabs: they land behind its staging
+    if constexpr (ACT_PRE) {
+      __builtin_amdgcn_sched_barrier(0);     // (not above the weight gradient: its fragments need the registers)
+      if (tile + (int)gridDim.x < n_tiles) fetch_act(tile + gridDim.x, tid);
+    }
     __syncthreads();
     PI_STAMP(13);
   }

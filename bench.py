@@ -283,6 +283,23 @@ def time_update(policy, res, n, reps=3):
     return float(np.median(times[1:])), info
 
 
+def time_fvp(policy, reps=5):
+    """One Fisher-vector product (direction pack + pi_kernel<FVP> on the saved activations + the fixed-order sum of the
+    workgroups' partials) on the batch the last update_policy left bound; ms per product by events on the launch stream."""
+    ops = policy.ops
+    with torch.cuda.device(ops.device):
+        ops.loss_grad(0)                       # saves the hidden activations, as the update's first gradient does
+        ops.dirv.normal_()
+        ops.fvp_raw(ops.dirv)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.fvp_raw(ops.dirv)
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
 def time_train_steps(pe, x, t, batch, steps):
     """Ensemble training: average microseconds of one train_op (forward, loss, backward, weight
     gradients, Adam) with per-member bootstrap rows of device-resident data."""
@@ -506,8 +523,11 @@ def main():
         n50 = min(50000, n_full)
         upd_ms_50k, upd_info = time_update(policy, res, n50)
         upd_ms_full, _ = time_update(policy, res, n_full, reps=2)
+        from cmbpo_amd import _lib as _l
         upd = {"unit": "ms", "n_50k": n50, "ms_50k": upd_ms_50k, "n_full": n_full, "ms_full": upd_ms_full,
-               "optim_case": int(upd_info["OptimCase"]), "hvps": int(upd_info["n_fvp"]), "per_rank": True}
+               "optim_case": int(upd_info["OptimCase"]), "hvps": int(upd_info["n_fvp"]), "per_rank": True,
+               "fvp_ms_full": time_fvp(policy),
+               "matrix_path": "3 x v_mfma_f32_32x32x16_f16 per f32 product" if _l.lib().cmbpo_get_pi_matrix_path() else "fp32 MFMA"}
         # Metric C: ensemble training steps (dynamics model on (obs, act) -> (d_obs, rew); critic on obs -> ret)
         obs_t, act_t, ret_t = res[0], res[1], res[4]
         n_tr = min(n_full, 200000)

@@ -741,6 +741,8 @@ int launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s, int head_override 
 
   if (g_split_path == CMBPO_ENS_SPLIT_F16 && head == CMBPO_HEAD_PROB && cmbpo_internal_h3_eligible(m) && a.n_rows >= g_h3_min_rows)
     return cmbpo_internal_launch_h3(m, a, s);
+  if (g_split_path == CMBPO_ENS_SPLIT_F16 && head == CMBPO_HEAD_GAUSS_PI && cmbpo_internal_policy_f16_eligible(m))
+    return cmbpo_internal_launch_policy_f16(m, a, s);      // the actor on the same arithmetic (policy_f16.hip)
   if (head == CMBPO_HEAD_PROB && H == 512 && m->act == CMBPO_ACT_SWISH && m->o_tiles <= 4 && m->in_pad <= 64 && g_split_path)
     return cmbpo_internal_launch_split(m, a, s);
   // (the critics' split kernel pays from ~30 k rows: below that a launch is one round of items and an item's latency

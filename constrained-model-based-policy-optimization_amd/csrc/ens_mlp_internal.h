@@ -76,5 +76,8 @@ int cmbpo_internal_launch_split(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s);
 // HEAD_PROB, 512-wide, swish: the same forward with three f16 MFMAs per float32 product, 128-row items (ens_h3.hip)
 bool cmbpo_internal_h3_eligible(const cmbpo_mlp *m);
 int cmbpo_internal_launch_h3(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s);
+// the actor (128-wide tanh + gaussian head, one member) on the three-term f16 path (policy_f16.hip)
+bool cmbpo_internal_policy_f16_eligible(const cmbpo_mlp *m);
+int cmbpo_internal_launch_policy_f16(cmbpo_mlp *m, const MlpKernelArgs &a, hipStream_t s);
 // HEAD_DETMEAN, 128-wide, swish, one output (the critics) on the same matrix path
 int cmbpo_internal_launch_critic_split(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s);

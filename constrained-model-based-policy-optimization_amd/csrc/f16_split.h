@@ -35,6 +35,22 @@ __device__ __forceinline__ void mm3(f32x16 &acc, const f16x8 &a1, const f16x8 &a
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
 }
 
+// ---- two floats x t -> their two f16 pieces, packed ------------------------------------------------------------------
+// p1 = f16(x t), p2 = f16(x t - p1): one v_fma_mix each (see the epilogue below).  HAZ: the pieces feed an MFMA straight from
+// the registers -- hipcc pads no hazard behind an asm statement, so the wait states stand inside the strings of the high halves.
+template <bool HAZ>
+__device__ __forceinline__ void split2(float x0, float x1, float t, unsigned &q1, unsigned &q2) {
+  unsigned a, b;   // (the low halves are written first: "=&v", the registers need no initial value)
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(a) : "v"(x0), "v"(t));
+  if constexpr (HAZ) asm("v_fma_mixhi_f16 %0, %1, %2, 0\n\ts_nop 1" : "+v"(a) : "v"(x1), "v"(t));
+  else asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(a) : "v"(x1), "v"(t));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(b) : "v"(x0), "v"(t), "v"(a));
+  if constexpr (HAZ) asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\ts_nop 1" : "+v"(b) : "v"(x1), "v"(t), "v"(a));
+  else asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(b) : "v"(x1), "v"(t), "v"(a));
+  q1 = a;
+  q2 = b;
+}
+
 // ---- the swish / lift / split epilogue of four accumulator values, cut into twelve pieces of at most ~20 issue cycles
 // so that one piece can stand behind each MFMA of a 12-MFMA group (a wave issues in order: what stands between two MFMAs
 // runs in the shadow of the first).  The split uses the mixed-precision FMAs: p1 = f16(x t) and p2 = f16(x t - p1) are

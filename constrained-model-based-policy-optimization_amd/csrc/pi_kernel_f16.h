@@ -35,21 +35,7 @@ __device__ __forceinline__ void static_for(F &&f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// ---- splits ---------------------------------------------------------------------------------------------------------
-// p1 = f16(x t), p2 = f16(x t - p1): one v_fma_mix each (f16_split.h).  HAZ: the pieces feed an MFMA straight from the
-// registers -- hipcc pads no hazard behind an asm statement, so the wait states stand inside the strings of the high halves.
-template <bool HAZ>
-__device__ __forceinline__ void split2(float x0, float x1, float t, unsigned &q1, unsigned &q2) {
-  unsigned a, b;   // (the low halves are written first: "=&v", the registers need no initial value)
-  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(a) : "v"(x0), "v"(t));
-  if constexpr (HAZ) asm("v_fma_mixhi_f16 %0, %1, %2, 0\n\ts_nop 1" : "+v"(a) : "v"(x1), "v"(t));
-  else asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(a) : "v"(x1), "v"(t));
-  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(b) : "v"(x0), "v"(t), "v"(a));
-  if constexpr (HAZ) asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\ts_nop 1" : "+v"(b) : "v"(x1), "v"(t), "v"(a));
-  else asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(b) : "v"(x1), "v"(t), "v"(a));
-  q1 = a;
-  q2 = b;
-}
+// (split2<HAZ>: f16_split.h)
 __device__ __forceinline__ void split8(const f32x4 &lo, const f32x4 &hi, float t, f16x8 &p1, f16x8 &p2) {
   unsigned a[4], b[4];
   split2<true>(lo[0], lo[1], t, a[0], b[0]);

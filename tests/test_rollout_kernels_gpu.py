@@ -134,8 +134,12 @@ def test_critic_predict_mean(hip_lib, ens_path, n, obs_dim):
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("ens_path", [0, 2], indirect=True, ids=["fp32mfma", "splitf16"])
+@pytest.mark.parametrize("n", [333, 1, 129, 4100])
 @pytest.mark.parametrize("task", ["AntSafe-v2", "HumanoidSafe-v2", "HopperSafe-v2"])
-def test_policy_forward(hip_lib, task):
+def test_policy_forward(hip_lib, ens_path, task, n):
+    """cmbpo_policy_forward on both matrix paths (the general fp32-MFMA kernel; policy_f16.hip: one wave per 32-row tile,
+    three f16 MFMAs per product), with and without a row list."""
     _cuda()
     from cmbpo_amd import synthetic
     from cmbpo_amd.cpo_policy import GaussianActor
@@ -147,8 +151,8 @@ def test_policy_forward(hip_lib, task):
     params[6] = rng.uniform(-1.0, 0.0, act_dim).astype(np.float32)
     actor = GaussianActor(obs_dim, act_dim, (128, 128), device="cuda:0")
     actor.set_params(params)
-    n = 333
     obs = rng.standard_normal((n, obs_dim)).astype(np.float32)
+    obs[n // 2] *= 1e3                                     # one row far outside the others' range (its own lift)
     eps = rng.standard_normal((n, act_dim)).astype(np.float32)
     dev = actor.device
     f = dict(dtype=torch.float32, device=dev)
@@ -159,6 +163,17 @@ def test_policy_forward(hip_lib, task):
     for k in ("pi", "mu", "logp_pi", "log_std"):
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=1e-4, atol=1e-4, err_msg=k)
     np.testing.assert_array_equal(out["log_std"].cpu().numpy(), ref["log_std"])
+    if n >= 129:
+        # a row list (the sampler's alive list): only the listed slots are evaluated and written
+        idx = np.sort(rng.choice(n, size=n // 3, replace=False)).astype(np.int32)
+        out2 = {k: torch.full_like(v, -7.0) for k, v in out.items()}
+        actor.forward_device(torch.from_numpy(obs).to(dev), torch.from_numpy(eps).to(dev), out2,
+                             row_idx=torch.from_numpy(idx).to(dev), n_rows=len(idx))
+        rest = np.setdiff1d(np.arange(n), idx)
+        for k in ("pi", "mu", "logp_pi"):
+            got = out2[k].cpu().numpy()
+            np.testing.assert_array_equal(got[idx], out[k].cpu().numpy()[idx], err_msg=k)
+            assert np.all(got[rest] == -7.0), k
 
 
 def _post_inputs(rng, task, n, E=7):

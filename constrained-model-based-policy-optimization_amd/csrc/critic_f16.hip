@@ -13,6 +13,7 @@
 #include "common.h"
 #include "ens_mlp_internal.h"
 #include "f16_split.h"
+#include "policy_f16_tile.h"
 
 namespace {
 
@@ -36,6 +37,10 @@ struct CfArgs {
   int obs_dim, ensemble;
   const int32_t *row_idx, *n_rows_dev;
   int n_rows;
+  // optional rider: one more wave per tile evaluates the actor at the same rows (the NEXT step's action at the observation
+  // the critics are evaluated at -- the step after this one then starts without a policy launch)
+  int has_pol;
+  PfArgs pol;
 };
 
 template <int S0>   // k-slabs of the input layer (obs_dim <= 16 S0)
@@ -52,7 +57,8 @@ __global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
   const int n_rows = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
   const int row0 = blockIdx.x * 32;
   if (row0 >= n_rows) return;
-  const int ni = wave / E, e = wave - ni * E;     // this wave's critic and member
+  const bool is_pol = wave == 2 * E;              // (only launched with has_pol)
+  const int ni = is_pol ? 0 : wave / E, e = is_pol ? 0 : wave - ni * E;     // this wave's critic and member
   const CfNet &N = a.net[ni];
   // first weight fragments of layer 0: requested before anything else
   const f16x8 *w0 = N.w0 + (size_t)e * N.w0_stride + lane;      // + ((tile * S0 + s) * 2 + piece) * 64
@@ -69,10 +75,12 @@ __global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
       x[t][0] = q[0]; x[t][1] = q[64];
     }
   };
+  if (!is_pol) {
 #pragma unroll
-  for (int s = 0; s < S0; ++s) load_w(A0[s], w0, S0, s);
+    for (int s = 0; s < S0; ++s) load_w(A0[s], w0, S0, s);
 #pragma unroll
-  for (int s = 0; s < RW; ++s) load_w(R[s], w1, S1, s);
+    for (int s = 0; s < RW; ++s) load_w(R[s], w1, S1, s);
+  }
   if (tid < 32) {
     const int rr = row0 + tid;
     int v = rr < n_rows ? rr : 0;
@@ -94,6 +102,11 @@ __global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
     xraw[b * (KP + 1) + k] = (rr >= 0 && k < a.obs_dim) ? x : 0.0f;
   }
   __syncthreads();
+  if (is_pol) {
+    policy_tile<S0, true>(a.pol, row0, n_rows, xraw, rows, lane);
+    __syncthreads();      // (the critics' barrier before the member mean)
+    return;
+  }
   const float *st = N.stats + (size_t)e * NSTAT;
 
   // ---- input fragment: this critic's scaler, the row's lift, the split -- in registers ---------------------------------
@@ -237,6 +250,20 @@ extern "C" int cmbpo_critic_pair_supported(const cmbpo_mlp_t *v, const cmbpo_mlp
 
 extern "C" int cmbpo_critic_pair_predict(cmbpo_mlp_t *v, cmbpo_mlp_t *vc, const float *d_obs, int obs_dim, const int32_t *d_row_idx,
                                          const int32_t *d_n_rows, int n_rows, float *d_v, float *d_vc, void *stream) {
+  return cmbpo_internal_critic_pair_ride(v, vc, d_obs, obs_dim, d_row_idx, d_n_rows, n_rows, d_v, d_vc, nullptr, nullptr, nullptr,
+                                         nullptr, nullptr, nullptr, stream);
+}
+
+// can the actor ride along? (its f16 kernel applies, same input width, room for one more wave)
+bool cmbpo_internal_critic_pair_can_ride(const cmbpo_mlp *v, const cmbpo_mlp *vc, const cmbpo_mlp *policy) {
+  return cmbpo_critic_pair_supported(v, vc) && policy && cmbpo_internal_policy_f16_eligible(policy) && policy->in_dim == v->in_dim &&
+         2 * v->ensemble + 1 <= 8 && cmbpo_get_ens_matrix_path() == CMBPO_ENS_SPLIT_F16;
+}
+
+// the critics at d_obs and -- if policy != NULL -- the actor at the same rows in the same launch (d_eps, outputs slot indexed)
+int cmbpo_internal_critic_pair_ride(cmbpo_mlp *v, cmbpo_mlp *vc, const float *d_obs, int obs_dim, const int32_t *d_row_idx,
+                                    const int32_t *d_n_rows, int n_rows, float *d_v, float *d_vc, cmbpo_mlp *policy,
+                                    const float *d_eps, float *d_pi, float *d_logp, float *d_mu, float *d_ls, void *stream) {
   CMBPO_REQUIRE(v && vc && d_obs && d_v && d_vc, "cmbpo_critic_pair_predict: NULL argument");
   CMBPO_REQUIRE(cmbpo_critic_pair_supported(v, vc), "cmbpo_critic_pair_predict: needs two loaded 128-wide swish ensembles of equal "
                                                     "size with one output (HEAD_DETMEAN)");
@@ -269,7 +296,18 @@ extern "C" int cmbpo_critic_pair_predict(cmbpo_mlp_t *v, cmbpo_mlp_t *vc, const 
   a.obs = d_obs; a.obs_dim = obs_dim; a.ensemble = v->ensemble;
   a.row_idx = d_row_idx; a.n_rows_dev = d_n_rows; a.n_rows = n_rows;
   const int S0 = ms[0]->h3_s0;
-  const int threads = 64 * 2 * v->ensemble;
+  a.has_pol = 0;
+  if (policy != nullptr) {
+    CMBPO_REQUIRE(cmbpo_internal_critic_pair_can_ride(v, vc, policy) && d_eps && d_pi && d_logp && d_mu && d_ls,
+                  "critic pair: the actor cannot ride along (shape / path) or a NULL buffer");
+    int ps0 = 0;
+    if (int rc = cmbpo_internal_policy_f16_args(policy, &a.pol, &ps0, s)) return rc;
+    CMBPO_REQUIRE(ps0 == S0, "critic pair: actor and critics disagree on the input slabs (%d, %d)", ps0, S0);
+    a.pol.obs = d_obs; a.pol.eps = d_eps; a.pol.row_idx = d_row_idx; a.pol.n_rows_dev = d_n_rows; a.pol.n_rows = n_rows;
+    a.pol.pi = d_pi; a.pol.logp = d_logp; a.pol.mu = d_mu; a.pol.ls = d_ls;
+    a.has_pol = 1;
+  }
+  const int threads = 64 * (2 * v->ensemble + a.has_pol);
   const size_t lds = ((size_t)32 * (16 * S0 + 1) + (size_t)2 * v->ensemble * 32) * sizeof(float);
   const int grid = cmbpo_ceil_div(n_rows, 32);
   if (S0 == 2) hipLaunchKernelGGL(critic_pair_kernel<2>, dim3(grid), dim3(threads), lds, s, a);

@@ -8,173 +8,20 @@
 #include "ens_mlp_internal.h"
 #include "f16_split.h"
 
+#include "policy_f16_tile.h"
+
 namespace {
 
-constexpr int HP = 128;          // hidden units
-constexpr int NTP = HP / 32;     // n-tiles
-constexpr int SP1 = HP / 16;     // k-slabs of the hidden-width products
-constexpr float T_H = 16384.0f;  // lift of a tanh output
-
-struct PfArgs {
-  const f16x8 *w0, *w1, *w2;     // images [n-tile][slab][piece][lane]
-  const float *b0, *b1, *b2, *log_std, *stats;
-  const float *obs, *eps;
-  int obs_dim, act_dim;
-  const int32_t *row_idx, *n_rows_dev;
-  int n_rows;
-  float *pi, *logp, *mu, *ls;
-};
-
-// four accumulator values -> tanh(d inv + b) -> lifted, split, packed (two dwords per piece)
-__device__ __forceinline__ void tanh_split4(const f32x16 &d, int q, float inv, const f32x4 &bv, unsigned (&q1)[2], unsigned (&q2)[2]) {
-  float h[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) h[i] = cmbpo_fast_tanh(__builtin_fmaf(d[4 * q + i], inv, bv[i]));
-  split2<true>(h[0], h[1], T_H, q1[0], q2[0]);
-  split2<true>(h[2], h[3], T_H, q1[1], q2[1]);
-}
-
-template <int S0>   // k-slabs of the input layer (obs_dim <= 16 S0)
+template <int S0>
 __global__ __launch_bounds__(256, 2) void policy_f16_kernel(const PfArgs a) {
   constexpr int KP = 16 * S0;
   extern __shared__ float sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, hh = lane >> 5;
-  float *xraw = sm + wave * (32 * (KP + 1));    // [32][KP + 1] raw observation rows of this wave's tile
   __shared__ int rows_s[4][32];
-  int *rows = rows_s[wave];
   const int n_rows = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
   const int row0 = (blockIdx.x * 4 + wave) * 32;
-  if (row0 >= n_rows) return;                   // (waves are independent: no workgroup barrier below)
-  const f16x8 *w0 = a.w0 + lane, *w1 = a.w1 + lane, *w2 = a.w2 + lane;
-  // all of W0 and the first slabs of W1 are requested before the rows are staged (critic_f16.hip)
-  constexpr int RW = S0 <= 2 ? 3 : 2;
-  f16x8 A0[S0][NTP][2], R[3][NTP][2];
-  auto load_w = [&](f16x8 (&x)[NTP][2], const f16x8 *w, int slabs, int s) {
-#pragma unroll
-    for (int t = 0; t < NTP; ++t) {
-      const f16x8 *q = w + ((size_t)(t * slabs + s) * 2) * 64;
-      x[t][0] = q[0]; x[t][1] = q[64];
-    }
-  };
-#pragma unroll
-  for (int s = 0; s < S0; ++s) load_w(A0[s], w0, S0, s);
-#pragma unroll
-  for (int s = 0; s < RW; ++s) load_w(R[s], w1, SP1, s);
-  if (lane < 32) {
-    const int rr = row0 + lane;
-    int v = rr < n_rows ? rr : 0;
-    if (a.row_idx) v = a.row_idx[v];
-    rows[lane] = rr < n_rows ? v : -1;
-  }
-  __builtin_amdgcn_wave_barrier();
-  for (int i = lane; i < 32 * KP; i += 64) {      // unconditional loads (clamped), the selection is on the values
-    const int b = i / KP, k = i - b * KP;
-    const int rr = rows[b];
-    const float x = a.obs[(size_t)(rr >= 0 ? rr : 0) * a.obs_dim + (k < a.obs_dim ? k : 0)];
-    xraw[b * (KP + 1) + k] = (rr >= 0 && k < a.obs_dim) ? x : 0.0f;
-  }
-  __builtin_amdgcn_wave_barrier();
-  const float *st = a.stats;
-
-  // ---- input fragment: the row's lift, the split -- in registers -------------------------------------------------------
-  float xs[S0][8];
-  float m0 = 0.0f;
-#pragma unroll
-  for (int s = 0; s < S0; ++s)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float x = xraw[r * (KP + 1) + 16 * s + 8 * hh + j];
-      xs[s][j] = x;
-      m0 = fmaxf(m0, fabsf(x));
-    }
-  m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));
-  const float t0 = pow2_lift(m0);
-  const float inv0 = 1.0f / (st[0] * t0), inv1 = 1.0f / (st[4] * T_H), inv2 = 1.0f / (st[8] * T_H);
-
-  f32x16 acc[NTP];
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int t = 0; t < NTP; ++t)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-  };
-  zero_acc();
-  // ---- layer 0 -------------------------------------------------------------------------------------------------------------
-#pragma unroll
-  for (int s = 0; s < S0; ++s) {
-    unsigned c1[4], c2[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) split2<true>(xs[s][2 * j], xs[s][2 * j + 1], t0, c1[j], c2[j]);
-    const u32x4 u1 = {c1[0], c1[1], c1[2], c1[3]}, u2 = {c2[0], c2[1], c2[2], c2[3]};
-    const f16x8 b1 = __builtin_bit_cast(f16x8, u1), b2 = __builtin_bit_cast(f16x8, u2);
-#pragma unroll
-    for (int t = 0; t < NTP; ++t) mm3(acc[t], A0[s][t][0], A0[s][t][1], b1, b2);
-  }
-  // ---- a hidden layer's accumulators -> tanh -> the next product's B fragments: registers 8 half .. + 7 of tile t are slab
-  // 2 t + half
-  f16x8 bf[SP1][2];
-  auto to_frags = [&](const float *bias, float inv) {
-    u32x4 bu[SP1][2];
-#pragma unroll
-    for (int t = 0; t < NTP; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + 32 * t + 8 * q + 4 * hh);
-        unsigned q1[2], q2[2];
-        tanh_split4(acc[t], q, inv, bv, q1, q2);
-        const int S = 2 * t + (q >> 1), o = 2 * (q & 1);
-        bu[S][0][o] = q1[0]; bu[S][0][o + 1] = q1[1];
-        bu[S][1][o] = q2[0]; bu[S][1][o + 1] = q2[1];
-      }
-#pragma unroll
-    for (int S = 0; S < SP1; ++S) { bf[S][0] = __builtin_bit_cast(f16x8, bu[S][0]); bf[S][1] = __builtin_bit_cast(f16x8, bu[S][1]); }
-  };
-  to_frags(a.b0, inv0);
-  zero_acc();
-  // ---- layer 1 (its first fragments arrived behind layer 0 and the epilogue) ------------------------------------------------
-  if constexpr (RW < 3) load_w(R[2], w1, SP1, 2);      // (the third ring slot: free now that W0 is consumed)
-#pragma unroll
-  for (int s = 0; s < SP1; ++s) {
-#pragma unroll
-    for (int t = 0; t < NTP; ++t) mm3(acc[t], R[s % 3][t][0], R[s % 3][t][1], bf[s][0], bf[s][1]);
-    if (s + 3 < SP1) load_w(R[s % 3], w1, SP1, s + 3);
-  }
-  // the output layer is one n-tile: its eight slabs (two pieces each) are requested while the epilogue runs
-  f16x8 W2[SP1][2];
-#pragma unroll
-  for (int s = 0; s < SP1; ++s) { W2[s][0] = w2[(size_t)(2 * s) * 64]; W2[s][1] = w2[(size_t)(2 * s + 1) * 64]; }
-  to_frags(a.b1, inv1);
-  // ---- mu = h2 W2 + b2 ----------------------------------------------------------------------------------------------------
-  f32x16 o;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) o[i] = 0.0f;
-#pragma unroll
-  for (int s = 0; s < SP1; ++s) mm3(o, W2[s][0], W2[s][1], bf[s][0], bf[s][1]);
-  // ---- head: accumulator register 4 q + e of lane (r, hh) is action 8 q + 4 hh + e of row r -----------------------------
-  const int rr = rows[r];
-  const int A = a.act_dim;
-  float lp = 0.0f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int ac = 8 * q + 4 * hh + e;
-      if (ac < A && rr >= 0) {
-        const float mu = __builtin_fmaf(o[4 * q + e], inv2, a.b2[ac]);
-        const float ls = a.log_std[ac];
-        const float sd = expf(ls);
-        const size_t at = (size_t)rr * A + ac;
-        const float pi = mu + a.eps[at] * sd;
-        const float z = (pi - mu) / (sd + 1e-8f);
-        lp += -0.5f * (z * z + 2.0f * ls + 1.8378770664093453f);   // gaussian_likelihood, network/ac_network.py:46-48
-        a.pi[at] = pi;
-        a.mu[at] = mu;
-        a.ls[at] = ls;
-      }
-    }
-  lp += __shfl_xor(lp, 32, 64);
-  if (hh == 0 && rr >= 0) a.logp[rr] = lp;
+  if (row0 >= n_rows) return;                   // (waves are independent: no workgroup barrier)
+  policy_tile<S0, false>(a, row0, n_rows, sm + wave * (32 * (KP + 1)), rows_s[wave], lane);
 }
 
 bool policy_eligible(const cmbpo_mlp *m) {
@@ -218,20 +65,29 @@ int ensure_pf16(cmbpo_mlp *m, hipStream_t s) {
 
 bool cmbpo_internal_policy_f16_eligible(const cmbpo_mlp *m) { return policy_eligible(m); }
 
-int cmbpo_internal_launch_policy_f16(cmbpo_mlp *m, const MlpKernelArgs &k, hipStream_t s) {
+// the kernel arguments of the actor's images (built / refreshed on the way); *s0_out = k-slabs of its input layer
+int cmbpo_internal_policy_f16_args(cmbpo_mlp *m, void *pf_args, int *s0_out, hipStream_t s) {
   const int s0 = (m->in_pad + 15) / 16;
   if (m->h3_s0 == 0) m->h3_s0 = s0 < 2 ? 2 : s0;
   if (int rc = ensure_pf16(m, s)) return rc;
   const float *blob = m->d_blob;
   const f16x8 *base = reinterpret_cast<const f16x8 *>(m->d_h3);
-  PfArgs a{};
+  PfArgs &a = *static_cast<PfArgs *>(pf_args);
   a.w0 = base + m->h3_off[0]; a.w1 = base + m->h3_off[1]; a.w2 = base + m->h3_off[2];
   a.b0 = blob + m->off_b0; a.b1 = blob + m->off_b1; a.b2 = blob + m->off_b2; a.log_std = blob + m->off_log_std;
   a.stats = reinterpret_cast<const float *>(reinterpret_cast<const char *>(m->d_h3) + m->h3_stats_off * 16);
-  a.obs = k.obs; a.eps = k.eps; a.obs_dim = k.obs_dim; a.act_dim = m->out_dim;
+  a.obs_dim = m->in_dim; a.act_dim = m->out_dim;
+  *s0_out = m->h3_s0;
+  return CMBPO_OK;
+}
+
+int cmbpo_internal_launch_policy_f16(cmbpo_mlp *m, const MlpKernelArgs &k, hipStream_t s) {
+  PfArgs a{};
+  int S0 = 0;
+  if (int rc = cmbpo_internal_policy_f16_args(m, &a, &S0, s)) return rc;
+  a.obs = k.obs; a.eps = k.eps; a.obs_dim = k.obs_dim;
   a.row_idx = k.row_idx; a.n_rows_dev = k.n_rows_dev; a.n_rows = k.n_rows;
   a.pi = k.out0; a.logp = k.out1; a.mu = k.out2; a.ls = k.out3;
-  const int S0 = m->h3_s0;
   const size_t lds = (size_t)4 * 32 * (16 * S0 + 1) * sizeof(float);
   const int grid = cmbpo_ceil_div(k.n_rows, 128);
   if (S0 == 2) hipLaunchKernelGGL(policy_f16_kernel<2>, dim3(grid), dim3(256), lds, s, a);

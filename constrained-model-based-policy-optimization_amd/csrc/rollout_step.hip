@@ -4,16 +4,22 @@
 // rollout batch sizes of the shipped configs (1e3 - 1e4 branches) a step is bound by host latency, not by the kernels.
 // Every buffer is a field of the rollout struct; nothing here adds arithmetic.
 #include "common.h"
+#include "ens_mlp_internal.h"
 
-extern "C" int cmbpo_rollout_step(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy, cmbpo_mlp_t *model,
-                                  cmbpo_mlp_t *v, cmbpo_mlp_t *vc, int task, int ensemble, const float *d_eps,
-                                  const int32_t *d_elite, float *d_mean, float *d_var, void *stream) {
+// policy_ready: this step's actions are already in act_t / logp_t / mu_t / ls_t (the previous step's critic launch carried
+// the actor along).  d_eps_next != NULL: let this step's critic launch carry the actor for the NEXT step (its noise), if the
+// three networks allow it; *next_ready says whether it did.
+static int step_impl(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy, cmbpo_mlp_t *model, cmbpo_mlp_t *v,
+                     cmbpo_mlp_t *vc, int task, int ensemble, const float *d_eps, const int32_t *d_elite, float *d_mean,
+                     float *d_var, bool policy_ready, const float *d_eps_next, bool *next_ready, void *stream) {
   CMBPO_REQUIRE(r && policy && model && v && vc && d_eps && d_elite && d_mean && d_var, "cmbpo_rollout_step: NULL argument");
   CMBPO_REQUIRE(n_alive >= 1 && n_alive <= r->B, "cmbpo_rollout_step: n_alive %d not in [1, B=%d]", n_alive, r->B);
   // the per-step arrays are inputs of the bookkeeping kernels (const in the struct) and outputs of the forward passes
   auto w = [](const float *p) { return const_cast<float *>(p); };
   int rc;
-  if ((rc = cmbpo_policy_forward(policy, r->cur_obs, r->obs_dim, d_eps, r->alive_idx, nullptr, n_alive, w(r->act_t), w(r->logp_t),
+  *next_ready = false;
+  if (!policy_ready &&
+      (rc = cmbpo_policy_forward(policy, r->cur_obs, r->obs_dim, d_eps, r->alive_idx, nullptr, n_alive, w(r->act_t), w(r->logp_t),
                                  w(r->mu_t), w(r->ls_t), stream)))
     return rc;
   if ((rc = cmbpo_ens_forward(model, r->cur_obs, r->obs_dim, r->act_t, r->act_dim, r->alive_idx, nullptr, n_alive, r->B,
@@ -31,8 +37,14 @@ extern "C" int cmbpo_rollout_step(const cmbpo_rollout_t *r, int n_alive, cmbpo_m
     if ((rc = cmbpo_rollout_store(r, stream))) return rc;
   }
   if (cmbpo_critic_pair_supported(v, vc)) {      // both critics in one launch (csrc/critic_f16.hip)
-    if ((rc = cmbpo_critic_pair_predict(v, vc, r->next_obs, r->obs_dim, r->alive_idx, nullptr, n_alive, w(r->v_n), w(r->vc_n), stream)))
+    // ... and, where it fits, the actor for the next step as one more wave per tile: both read next_obs, the store above has
+    // consumed this step's actions, and nothing below reads them
+    const bool ride = d_eps_next != nullptr && cmbpo_internal_critic_pair_can_ride(v, vc, policy);
+    if ((rc = cmbpo_internal_critic_pair_ride(v, vc, r->next_obs, r->obs_dim, r->alive_idx, nullptr, n_alive, w(r->v_n), w(r->vc_n),
+                                              ride ? policy : nullptr, d_eps_next, w(r->act_t), w(r->logp_t), w(r->mu_t), w(r->ls_t),
+                                              stream)))
       return rc;
+    *next_ready = ride;
   } else {
     if ((rc = cmbpo_ens_predict_mean(v, r->next_obs, r->obs_dim, r->alive_idx, nullptr, n_alive, w(r->v_n), stream))) return rc;
     if ((rc = cmbpo_ens_predict_mean(vc, r->next_obs, r->obs_dim, r->alive_idx, nullptr, n_alive, w(r->vc_n), stream))) return rc;
@@ -42,6 +54,13 @@ extern "C" int cmbpo_rollout_step(const cmbpo_rollout_t *r, int n_alive, cmbpo_m
     return 1;                                                              // the alive list has been rebuilt: swap it
   }
   return cmbpo_rollout_finish(r, 1, stream);
+}
+
+extern "C" int cmbpo_rollout_step(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy, cmbpo_mlp_t *model,
+                                  cmbpo_mlp_t *v, cmbpo_mlp_t *vc, int task, int ensemble, const float *d_eps,
+                                  const int32_t *d_elite, float *d_mean, float *d_var, void *stream) {
+  bool unused = false;
+  return step_impl(r, n_alive, policy, model, v, vc, task, ensemble, d_eps, d_elite, d_mean, d_var, false, nullptr, &unused, stream);
 }
 
 // Several steps in one call: what ModelSampler.sample()'s caller does between two steps (read the step's counters, swap the
@@ -60,9 +79,13 @@ extern "C" int cmbpo_rollout_run(cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *p
   CMBPO_REQUIRE(max_steps >= 1, "cmbpo_rollout_run: max_steps %d", max_steps);
   CMBPO_REQUIRE(!r->use_host_budget, "cmbpo_rollout_run: the cross-shard budget exchange needs the per-step path");
   int done = 0, swaps = 0;
+  bool ready = false;     // the actor for the step about to run was evaluated by the previous step's critic launch
   while (done < max_steps && n_alive > 0 && r->ptr < r->T) {
-    int rc = cmbpo_rollout_step(r, n_alive, policy, model, v, vc, task, ensemble, d_eps + (size_t)done * eps_stride,
-                                d_elite + (size_t)done * elite_stride, d_mean, d_var, stream);
+    const float *eps_next = done + 1 < max_steps ? d_eps + (size_t)(done + 1) * eps_stride : nullptr;
+    bool next_ready = false;
+    int rc = step_impl(r, n_alive, policy, model, v, vc, task, ensemble, d_eps + (size_t)done * eps_stride,
+                       d_elite + (size_t)done * elite_stride, d_mean, d_var, ready, eps_next, &next_ready, stream);
+    ready = next_ready;
     if (rc != 0 && rc != 1) return rc;
     char *h = static_cast<char *>(h_scalars) + (size_t)done * 384;
     if (int rc2 = cmbpo_rollout_read_scalars(r, h, stream)) return rc2;     // the host sync of the step

@@ -538,7 +538,10 @@ __global__ __launch_bounds__(256) void store_vec_kernel(const cmbpo_rollout_t r)
 // finish(POST) + compaction as one workgroup (small rollout batches): the horizon / environment-terminal finishes of
 // finish_kernel(mode 1), then the ordered alive list of the survivors into alive_idx_out.  The list is ALWAYS written (a
 // copy when nothing finished), so the host swaps alive_idx <-> alive_idx_out after every step without a second look.
-__global__ __launch_bounds__(kScanThreads) void book_post_kernel(const cmbpo_rollout_t r) {
+// host_out (optional): a host-mapped, coherent block of 128 dwords -- the step's counters (iscal | dscal, 96 dwords) are
+// written straight into it, then a system-scope fence, then `seq` at dword 96: the host polls that word instead of paying a
+// copy + a stream synchronisation per step (cmbpo_rollout_run)
+__global__ __launch_bounds__(kScanThreads) void book_post_kernel(const cmbpo_rollout_t r, uint32_t *host_out, uint32_t seq) {
   __shared__ int sm_i[17];
   __shared__ double sm_d[16];
   const int tid = threadIdx.x;
@@ -575,6 +578,18 @@ __global__ __launch_bounds__(kScanThreads) void book_post_kernel(const cmbpo_rol
   if (tid == 0) {
     r.iscal[CMBPO_I_N_ALIVE_OUT] = carry;
     r.iscal[CMBPO_I_N_ALIVE] = carry;           // the caller swaps alive_idx <-> alive_idx_out
+    if (host_out != nullptr) {
+      // (this thread wrote the last counters itself; the accumulators were left by book_pre_kernel, an earlier launch)
+      const uint4 *src = reinterpret_cast<const uint4 *>(r.iscal);      // iscal[32] | dscal[32]: one 384-byte block
+      uint4 *dst = reinterpret_cast<uint4 *>(host_out);
+      uint4 q[24];
+#pragma unroll
+      for (int i = 0; i < 24; ++i) q[i] = src[i];
+#pragma unroll
+      for (int i = 0; i < 24; ++i) dst[i] = q[i];
+      __threadfence_system();
+      *reinterpret_cast<volatile uint32_t *>(host_out + 96) = seq;
+    }
   }
 }
 
@@ -1010,7 +1025,21 @@ extern "C" int cmbpo_rollout_book_post(const cmbpo_rollout_t *r, int n_alive, vo
   CMBPO_REQUIRE(r->v_n && r->vc_n && r->term_t && r->rew_buf && r->val_buf && r->cost_buf && r->cval_buf && r->adv_buf &&
                     r->ret_buf && r->cadv_buf && r->cret_buf,
                 "cmbpo_rollout_book_post: NULL array");
-  hipLaunchKernelGGL(book_post_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r);
+  hipLaunchKernelGGL(book_post_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r, (uint32_t *)nullptr, 0u);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+// the same with the counters mirrored into host-mapped memory (d_host_out: device address of 128 dwords) and `seq` behind them
+int cmbpo_internal_book_post_mirror(const cmbpo_rollout_t *r, int n_alive, uint32_t *d_host_out, uint32_t seq, void *stream) {
+  if (int rc = check_rollout(r, "cmbpo_rollout_book_post")) return rc;
+  CMBPO_REQUIRE(n_alive >= 0 && n_alive <= kBookMax, "cmbpo_rollout_book_post: %d alive rows, at most %d", n_alive, kBookMax);
+  CMBPO_REQUIRE(r->v_n && r->vc_n && r->term_t && r->rew_buf && r->val_buf && r->cost_buf && r->cval_buf && r->adv_buf &&
+                    r->ret_buf && r->cadv_buf && r->cret_buf,
+                "cmbpo_rollout_book_post: NULL array");
+  CMBPO_REQUIRE(reinterpret_cast<const char *>(r->dscal) == reinterpret_cast<const char *>(r->iscal) + 128,
+                "cmbpo_rollout_book_post: iscal[32] and dscal[32] must be one 384-byte block");
+  hipLaunchKernelGGL(book_post_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r, d_host_out, seq);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }

@@ -6,12 +6,17 @@
 #include "common.h"
 #include "ens_mlp_internal.h"
 
+#include <string.h>
+
+int cmbpo_internal_book_post_mirror(const cmbpo_rollout_t *r, int n_alive, uint32_t *d_host_out, uint32_t seq, void *stream);
+
 // policy_ready: this step's actions are already in act_t / logp_t / mu_t / ls_t (the previous step's critic launch carried
 // the actor along).  d_eps_next != NULL: let this step's critic launch carry the actor for the NEXT step (its noise), if the
 // three networks allow it; *next_ready says whether it did.
 static int step_impl(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy, cmbpo_mlp_t *model, cmbpo_mlp_t *v,
                      cmbpo_mlp_t *vc, int task, int ensemble, const float *d_eps, const int32_t *d_elite, float *d_mean,
-                     float *d_var, bool policy_ready, const float *d_eps_next, bool *next_ready, void *stream) {
+                     float *d_var, bool policy_ready, const float *d_eps_next, bool *next_ready, uint32_t *d_mirror, uint32_t seq,
+                     void *stream) {
   CMBPO_REQUIRE(r && policy && model && v && vc && d_eps && d_elite && d_mean && d_var, "cmbpo_rollout_step: NULL argument");
   CMBPO_REQUIRE(n_alive >= 1 && n_alive <= r->B, "cmbpo_rollout_step: n_alive %d not in [1, B=%d]", n_alive, r->B);
   // the per-step arrays are inputs of the bookkeeping kernels (const in the struct) and outputs of the forward passes
@@ -50,7 +55,9 @@ static int step_impl(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy,
     if ((rc = cmbpo_ens_predict_mean(vc, r->next_obs, r->obs_dim, r->alive_idx, nullptr, n_alive, w(r->vc_n), stream))) return rc;
   }
   if (n_alive <= cmbpo_rollout_book_pre_max_rows() && !r->use_host_budget) {
-    if ((rc = cmbpo_rollout_book_post(r, n_alive, stream))) return rc;    // finish(POST) + compaction in one launch
+    // finish(POST) + compaction in one launch (with the step's counters mirrored to the host, if asked)
+    if ((rc = d_mirror ? cmbpo_internal_book_post_mirror(r, n_alive, d_mirror, seq, stream) : cmbpo_rollout_book_post(r, n_alive, stream)))
+      return rc;
     return 1;                                                              // the alive list has been rebuilt: swap it
   }
   return cmbpo_rollout_finish(r, 1, stream);
@@ -60,7 +67,8 @@ extern "C" int cmbpo_rollout_step(const cmbpo_rollout_t *r, int n_alive, cmbpo_m
                                   cmbpo_mlp_t *v, cmbpo_mlp_t *vc, int task, int ensemble, const float *d_eps,
                                   const int32_t *d_elite, float *d_mean, float *d_var, void *stream) {
   bool unused = false;
-  return step_impl(r, n_alive, policy, model, v, vc, task, ensemble, d_eps, d_elite, d_mean, d_var, false, nullptr, &unused, stream);
+  return step_impl(r, n_alive, policy, model, v, vc, task, ensemble, d_eps, d_elite, d_mean, d_var, false, nullptr, &unused, nullptr, 0u,
+                   stream);
 }
 
 // Several steps in one call: what ModelSampler.sample()'s caller does between two steps (read the step's counters, swap the
@@ -70,6 +78,51 @@ extern "C" int cmbpo_rollout_step(const cmbpo_rollout_t *r, int n_alive, cmbpo_m
 // reference's `alive_ratio <= 0.1`, algorithms/cmbpo.py:358-359), when total_samples reaches stop_total (>= 0; :356-357)
 // or when the buffer is full.  d_eps / d_elite: the draws of the first step, one step further every eps_stride /
 // elite_stride elements.  h_scalars: [max_steps][384 B] (pinned), the counters of every step taken.
+// Host-mapped mirror of a step's counters (one 512-byte slot per step of a call): the single-workgroup bookkeeping kernel that
+// ends a small-batch step writes them there and raises a sequence word; the host polls it.  NULL if the mapping cannot be had
+// (the copy + stream synchronisation of cmbpo_rollout_read_scalars is used instead).
+namespace {
+struct Mirror {
+  uint32_t *h = nullptr, *d = nullptr;
+  bool tried = false;
+};
+Mirror g_mirror;
+uint32_t g_seq = 0;
+constexpr int kMirrorSlots = 64, kMirrorDwords = 128;
+
+Mirror &mirror() {
+  if (!g_mirror.tried) {
+    g_mirror.tried = true;
+    const char *e = getenv("CMBPO_STEP_MIRROR");
+    if (e && e[0] == '0') return g_mirror;
+    void *h = nullptr, *d = nullptr;
+    if (hipHostMalloc(&h, (size_t)kMirrorSlots * kMirrorDwords * 4, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) == hipSuccess &&
+        hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+      memset(h, 0, (size_t)kMirrorSlots * kMirrorDwords * 4);
+      g_mirror.h = static_cast<uint32_t *>(h);
+      g_mirror.d = static_cast<uint32_t *>(d);
+    } else {
+      (void)hipGetLastError();
+      if (h) (void)hipHostFree(h);
+    }
+  }
+  return g_mirror;
+}
+
+// wait until the kernel raised `seq` in the slot; after ~2 s fall back to a stream synchronisation
+int wait_mirror(const uint32_t *slot, uint32_t seq, hipStream_t s) {
+  const volatile uint32_t *flag = slot + 96;
+  for (long spin = 0; spin < 400000000L; ++spin) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return CMBPO_OK;
+    __builtin_ia32_pause();
+  }
+  CMBPO_HIP_CHECK(hipStreamSynchronize(s));
+  if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return CMBPO_OK;
+  cmbpo_set_error("cmbpo_rollout_run: the step's counters never arrived in the host mirror");
+  return CMBPO_EHIP;
+}
+}  // namespace
+
 extern "C" int cmbpo_rollout_run(cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy, cmbpo_mlp_t *model, cmbpo_mlp_t *v,
                                  cmbpo_mlp_t *vc, int task, int ensemble, const float *d_eps, const int32_t *d_elite,
                                  long eps_stride, long elite_stride, float *d_mean, float *d_var, int max_steps,
@@ -83,12 +136,23 @@ extern "C" int cmbpo_rollout_run(cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *p
   while (done < max_steps && n_alive > 0 && r->ptr < r->T) {
     const float *eps_next = done + 1 < max_steps ? d_eps + (size_t)(done + 1) * eps_stride : nullptr;
     bool next_ready = false;
+    Mirror &mir = mirror();
+    const int slot = done % kMirrorSlots;
+    const uint32_t seq = ++g_seq ? g_seq : ++g_seq;      // never 0
+    uint32_t *d_slot = mir.d ? mir.d + (size_t)slot * kMirrorDwords : nullptr;
     int rc = step_impl(r, n_alive, policy, model, v, vc, task, ensemble, d_eps + (size_t)done * eps_stride,
-                       d_elite + (size_t)done * elite_stride, d_mean, d_var, ready, eps_next, &next_ready, stream);
+                       d_elite + (size_t)done * elite_stride, d_mean, d_var, ready, eps_next, &next_ready, d_slot, seq, stream);
     ready = next_ready;
     if (rc != 0 && rc != 1) return rc;
     char *h = static_cast<char *>(h_scalars) + (size_t)done * 384;
-    if (int rc2 = cmbpo_rollout_read_scalars(r, h, stream)) return rc2;     // the host sync of the step
+    if (rc == 1 && d_slot != nullptr) {
+      // small batch: the step's last kernel wrote the counters into the mirror -- wait for its sequence word
+      const uint32_t *h_slot = mir.h + (size_t)slot * kMirrorDwords;
+      if (int rc2 = wait_mirror(h_slot, seq, (hipStream_t)stream)) return rc2;
+      memcpy(h, h_slot, 384);
+    } else if (int rc2 = cmbpo_rollout_read_scalars(r, h, stream)) {         // the host sync of the step
+      return rc2;
+    }
     const int32_t *isc = reinterpret_cast<const int32_t *>(h);
     const double *dsc = reinterpret_cast<const double *>(h + 128);
     const int fin = isc[CMBPO_I_N_FIN_PRE] + isc[CMBPO_I_N_FIN_POST];

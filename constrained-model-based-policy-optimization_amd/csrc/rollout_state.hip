@@ -1030,6 +1030,28 @@ extern "C" int cmbpo_rollout_book_post(const cmbpo_rollout_t *r, int n_alive, vo
   return CMBPO_OK;
 }
 
+// the counters into the host mirror behind whatever ran before on the stream (large batches: the step ends with multi-workgroup
+// kernels, so a one-thread launch does what book_post_kernel's tail does for small ones)
+__global__ void scalars_mirror_kernel(const cmbpo_rollout_t r, uint32_t *host_out, uint32_t seq) {
+  const uint4 *src = reinterpret_cast<const uint4 *>(r.iscal);
+  uint4 *dst = reinterpret_cast<uint4 *>(host_out);
+  uint4 q[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) q[i] = src[i];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) dst[i] = q[i];
+  __threadfence_system();
+  *reinterpret_cast<volatile uint32_t *>(host_out + 96) = seq;
+}
+int cmbpo_internal_scalars_mirror(const cmbpo_rollout_t *r, uint32_t *d_host_out, uint32_t seq, void *stream) {
+  CMBPO_REQUIRE(r && r->iscal && r->dscal && d_host_out, "scalars mirror: NULL argument");
+  CMBPO_REQUIRE(reinterpret_cast<const char *>(r->dscal) == reinterpret_cast<const char *>(r->iscal) + 128,
+                "scalars mirror: iscal[32] and dscal[32] must be one 384-byte block");
+  hipLaunchKernelGGL(scalars_mirror_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, *r, d_host_out, seq);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
 // the same with the counters mirrored into host-mapped memory (d_host_out: device address of 128 dwords) and `seq` behind them
 int cmbpo_internal_book_post_mirror(const cmbpo_rollout_t *r, int n_alive, uint32_t *d_host_out, uint32_t seq, void *stream) {
   if (int rc = check_rollout(r, "cmbpo_rollout_book_post")) return rc;

@@ -9,6 +9,7 @@
 #include <string.h>
 
 int cmbpo_internal_book_post_mirror(const cmbpo_rollout_t *r, int n_alive, uint32_t *d_host_out, uint32_t seq, void *stream);
+int cmbpo_internal_scalars_mirror(const cmbpo_rollout_t *r, uint32_t *d_host_out, uint32_t seq, void *stream);
 
 // policy_ready: this step's actions are already in act_t / logp_t / mu_t / ls_t (the previous step's critic launch carried
 // the actor along).  d_eps_next != NULL: let this step's critic launch carry the actor for the NEXT step (its noise), if the
@@ -148,6 +149,11 @@ extern "C" int cmbpo_rollout_run(cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *p
     if (rc == 1 && d_slot != nullptr) {
       // small batch: the step's last kernel wrote the counters into the mirror -- wait for its sequence word
       const uint32_t *h_slot = mir.h + (size_t)slot * kMirrorDwords;
+      if (int rc2 = wait_mirror(h_slot, seq, (hipStream_t)stream)) return rc2;
+      memcpy(h, h_slot, 384);
+    } else if (d_slot != nullptr) {
+      const uint32_t *h_slot = mir.h + (size_t)slot * kMirrorDwords;
+      if (int rc2 = cmbpo_internal_scalars_mirror(r, d_slot, seq, stream)) return rc2;
       if (int rc2 = wait_mirror(h_slot, seq, (hipStream_t)stream)) return rc2;
       memcpy(h, h_slot, 384);
     } else if (int rc2 = cmbpo_rollout_read_scalars(r, h, stream)) {         // the host sync of the step

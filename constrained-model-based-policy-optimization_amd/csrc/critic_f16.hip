@@ -75,38 +75,41 @@ __global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
       x[t][0] = q[0]; x[t][1] = q[64];
     }
   };
-  if (!is_pol) {
-#pragma unroll
-    for (int s = 0; s < S0; ++s) load_w(A0[s], w0, S0, s);
-#pragma unroll
-    for (int s = 0; s < RW; ++s) load_w(R[s], w1, S1, s);
-  }
-  if (tid < 32) {
-    const int rr = row0 + tid;
-    int v = rr < n_rows ? rr : 0;
-    if (a.row_idx) v = a.row_idx[v];
-    rows[tid] = rr < n_rows ? v : -1;
-  }
-  if (tid < 2 * KP) {
-    const int n2 = tid / KP, k = tid - n2 * KP;
-    const CfNet &M = a.net[n2];
-    const int kc = k < a.obs_dim ? k : 0;
-    s_mu[n2][k] = (M.in_mu && k < a.obs_dim) ? M.in_mu[kc] : 0.0f;
-    s_sig[n2][k] = (M.in_mu && k < a.obs_dim) ? M.in_sig[kc] : 1.0f;
-  }
-  __syncthreads();
-  for (int i = tid; i < 32 * KP; i += blockDim.x) {      // unconditional loads (clamped), the selection is on the values
-    const int b = i / KP, k = i - b * KP;
-    const int rr = rows[b];
-    const float x = a.obs[(size_t)(rr >= 0 ? rr : 0) * a.obs_dim + (k < a.obs_dim ? k : 0)];
-    xraw[b * (KP + 1) + k] = (rr >= 0 && k < a.obs_dim) ? x : 0.0f;
-  }
-  __syncthreads();
+  // rows, scalers, raw observation rows: staged by every wave of the workgroup (two barriers)
+  auto stage = [&]() {
+    if (tid < 32) {
+      const int rr = row0 + tid;
+      int v = rr < n_rows ? rr : 0;
+      if (a.row_idx) v = a.row_idx[v];
+      rows[tid] = rr < n_rows ? v : -1;
+    }
+    if (tid < 2 * KP) {
+      const int n2 = tid / KP, k = tid - n2 * KP;
+      const CfNet &M = a.net[n2];
+      const int kc = k < a.obs_dim ? k : 0;
+      s_mu[n2][k] = (M.in_mu && k < a.obs_dim) ? M.in_mu[kc] : 0.0f;
+      s_sig[n2][k] = (M.in_mu && k < a.obs_dim) ? M.in_sig[kc] : 1.0f;
+    }
+    __syncthreads();
+    for (int i = tid; i < 32 * KP; i += blockDim.x) {      // unconditional loads (clamped), the selection is on the values
+      const int b = i / KP, k = i - b * KP;
+      const int rr = rows[b];
+      const float x = a.obs[(size_t)(rr >= 0 ? rr : 0) * a.obs_dim + (k < a.obs_dim ? k : 0)];
+      xraw[b * (KP + 1) + k] = (rr >= 0 && k < a.obs_dim) ? x : 0.0f;
+    }
+    __syncthreads();
+  };
   if (is_pol) {
-    policy_tile<S0, true>(a.pol, row0, n_rows, xraw, rows, lane);
+    // the actor's wave: its own first weight requests, then the common staging, then its tile
+    policy_tile<S0, true>(a.pol, row0, n_rows, xraw, rows, lane, stage);
     __syncthreads();      // (the critics' barrier before the member mean)
     return;
   }
+#pragma unroll
+  for (int s = 0; s < S0; ++s) load_w(A0[s], w0, S0, s);
+#pragma unroll
+  for (int s = 0; s < RW; ++s) load_w(R[s], w1, S1, s);
+  stage();
   const float *st = N.stats + (size_t)e * NSTAT;
 
   // ---- input fragment: this critic's scaler, the row's lift, the split -- in registers ---------------------------------

@@ -33,9 +33,12 @@ __device__ __forceinline__ void tanh_split4(const f32x16 &d, int q, float inv, c
 }
 
 // One wave, one 32-row tile.  STAGED: the tile's raw rows ([32][16 S0 + 1] floats) and slot ids (rows[32], -1 past the end) are
-// already in LDS (the critics' launch stages them for all its waves); otherwise this wave stages them itself.
-template <int S0, bool STAGED>   // S0: k-slabs of the input layer (obs_dim <= 16 S0)
-__device__ __forceinline__ void policy_tile(const PfArgs &a, int row0, int n_rows, float *xraw, int *rows, int lane) {
+// put into LDS by stage() (the critics' launch stages them with all its waves, barriers included: called here, behind this
+// wave's first weight requests); otherwise this wave stages them itself.
+struct NoStage { __device__ void operator()() const {} };
+template <int S0, bool STAGED, class STAGE = NoStage>   // S0: k-slabs of the input layer (obs_dim <= 16 S0)
+__device__ __forceinline__ void policy_tile(const PfArgs &a, int row0, int n_rows, float *xraw, int *rows, int lane,
+                                            STAGE &&stage = STAGE()) {
   constexpr int KP = 16 * S0;
   const int r = lane & 31, hh = lane >> 5;
   const f16x8 *w0 = a.w0 + lane, *w1 = a.w1 + lane, *w2 = a.w2 + lane;
@@ -61,13 +64,27 @@ __device__ __forceinline__ void policy_tile(const PfArgs &a, int row0, int n_row
       rows[lane] = rr < n_rows ? v : -1;
     }
     __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < 32 * KP; i += 64) {      // unconditional loads (clamped), the selection is on the values
-      const int b = i / KP, k = i - b * KP;
-      const int rr = rows[b];
-      const float x = a.obs[(size_t)(rr >= 0 ? rr : 0) * a.obs_dim + (k < a.obs_dim ? k : 0)];
-      xraw[b * (KP + 1) + k] = (rr >= 0 && k < a.obs_dim) ? x : 0.0f;
+    // unconditional loads (clamped), the selection is on the values; eight requests in flight per lane before the first
+    // LDS write (one at a time, the loop is sixteen global round trips long)
+    for (int base = 0; base < 32 * KP; base += 64 * 8) {
+      float xv[8];
+      bool ok[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + 64 * u + lane, b = i / KP, k = i - b * KP;
+        const int rr = rows[b];
+        xv[u] = a.obs[(size_t)(rr >= 0 ? rr : 0) * a.obs_dim + (k < a.obs_dim ? k : 0)];
+        ok[u] = rr >= 0 && k < a.obs_dim;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + 64 * u + lane, b = i / KP, k = i - b * KP;
+        xraw[b * (KP + 1) + k] = ok[u] ? xv[u] : 0.0f;
+      }
     }
     __builtin_amdgcn_wave_barrier();
+  } else {
+    stage();
   }
   const float *st = a.stats;
 
@@ -148,25 +165,42 @@ __device__ __forceinline__ void policy_tile(const PfArgs &a, int row0, int n_row
   // ---- head: accumulator register 4 q + e of lane (r, hh) is action 8 q + 4 hh + e of row r -----------------------------
   const int rr = rows[r];
   const int A = a.act_dim;
+  const int nq = (A + 7) >> 3;            // groups of 8 actions that exist: wave-uniform
+  const size_t rbase = (size_t)(rr >= 0 ? rr : 0) * A;
   float lp = 0.0f;
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < 4; ++q) {
+    if (q < nq) {
+      // every load of the group is requested before anything is computed, unconditionally (clamped): a load under a
+      // per-lane condition makes hipcc wait for each one in turn, and the head took five times as long as the rest of the tile
+      float ev[4], bv[4], lv[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int ac = 8 * q + 4 * hh + e;
-      if (ac < A && rr >= 0) {
-        const float mu = __builtin_fmaf(o[4 * q + e], inv2, a.b2[ac]);
-        const float ls = a.log_std[ac];
+      for (int e = 0; e < 4; ++e) {
+        const int ac = 8 * q + 4 * hh + e, acc = ac < A ? ac : A - 1;
+        ev[e] = a.eps[rbase + acc];
+        bv[e] = a.b2[acc];
+        lv[e] = a.log_std[acc];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ac = 8 * q + 4 * hh + e;
+        const bool valid = ac < A && rr >= 0;
+        const float mu = __builtin_fmaf(o[4 * q + e], inv2, bv[e]);
+        const float ls = lv[e];
         const float sd = expf(ls);
-        const size_t at = (size_t)rr * A + ac;
-        const float pi = mu + a.eps[at] * sd;
+        const float pi = mu + ev[e] * sd;
         const float z = (pi - mu) / (sd + 1e-8f);
-        lp += -0.5f * (z * z + 2.0f * ls + 1.8378770664093453f);   // gaussian_likelihood, network/ac_network.py:46-48
-        a.pi[at] = pi;
-        a.mu[at] = mu;
-        a.ls[at] = ls;
+        const float term = -0.5f * (z * z + 2.0f * ls + 1.8378770664093453f);   // gaussian_likelihood, network/ac_network.py:46-48
+        lp += valid ? term : 0.0f;
+        if (valid) {
+          const size_t at = rbase + ac;
+          a.pi[at] = pi;
+          a.mu[at] = mu;
+          a.ls[at] = ls;
+        }
       }
     }
+  }
   lp += __shfl_xor(lp, 32, 64);
   if (hh == 0 && rr >= 0) a.logp[rr] = lp;
 }

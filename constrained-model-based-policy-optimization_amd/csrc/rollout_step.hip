@@ -6,6 +6,7 @@
 #include "common.h"
 #include "ens_mlp_internal.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 int cmbpo_internal_book_post_mirror(const cmbpo_rollout_t *r, int n_alive, uint32_t *d_host_out, uint32_t seq, void *stream);
@@ -45,7 +46,8 @@ static int step_impl(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy,
   if (cmbpo_critic_pair_supported(v, vc)) {      // both critics in one launch (csrc/critic_f16.hip)
     // ... and, where it fits, the actor for the next step as one more wave per tile: both read next_obs, the store above has
     // consumed this step's actions, and nothing below reads them
-    const bool ride = d_eps_next != nullptr && cmbpo_internal_critic_pair_can_ride(v, vc, policy);
+    static const int ride_max = getenv("CMBPO_RIDE_MAX_ROWS") ? atoi(getenv("CMBPO_RIDE_MAX_ROWS")) : (1 << 30);
+    const bool ride = d_eps_next != nullptr && n_alive <= ride_max && cmbpo_internal_critic_pair_can_ride(v, vc, policy);
     if ((rc = cmbpo_internal_critic_pair_ride(v, vc, r->next_obs, r->obs_dim, r->alive_idx, nullptr, n_alive, w(r->v_n), w(r->vc_n),
                                               ride ? policy : nullptr, d_eps_next, w(r->act_t), w(r->logp_t), w(r->mu_t), w(r->ls_t),
                                               stream)))

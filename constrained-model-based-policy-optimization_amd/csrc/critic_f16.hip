@@ -15,6 +15,8 @@
 #include "f16_split.h"
 #include "policy_f16_tile.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int HC = 128;          // hidden units
@@ -209,6 +211,199 @@ __global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
   }
 }
 
+// ---- the same evaluation at large batches -----------------------------------------------------------------------------
+// critic_pair_kernel spends a tile's 15 us waiting: every wave streams its member's 80 KB of weights from L2 for 32 rows, one
+// workgroup per CU -- 190 us at 100 k rows, 12 rounds of tiles deep.  Here a workgroup owns a chunk of up to CH rows and takes
+// the 2 E members one after the other: a member's W0 | W1 images go to LDS once per workgroup (80 KB), its eight waves carry
+// the chunk's 32-row tiles with the A fragments read from LDS (the images are lane-linear: conflict-free 16-byte reads), the
+// member values are added per row in LDS in member order.  Per-member arithmetic exactly as in critic_pair_kernel: same bits.
+template <int S0>
+struct BigGeo {
+  static constexpr int KP = 16 * S0, XS = KP + 1;
+  static constexpr int CH = S0 <= 2 ? 512 : (S0 == 3 ? 256 : 192);    // rows per workgroup (LDS: weights + the chunk's rows)
+  static constexpr int W0Q = NT * S0 * 2 * 64, W1Q = NT * S1 * 2 * 64;   // f16x8 units
+  static constexpr size_t LDS = (size_t)(W0Q + W1Q) * 16 + (size_t)CH * XS * 4 + (size_t)2 * CH * 4 + (size_t)CH * 4 + (size_t)4 * KP * 4;
+};
+
+template <int S0>
+__global__ __launch_bounds__(512) void critic_big_kernel(const CfArgs a, int ch_rows) {
+  using G = BigGeo<S0>;
+  constexpr int KP = G::KP, XS = G::XS;
+  extern __shared__ f16x8 smem8[];
+  f16x8 *w0s = smem8, *w1s = w0s + G::W0Q;
+  float *xraw = reinterpret_cast<float *>(w1s + G::W1Q);   // [ch_rows][XS]
+  float *vsum = xraw + G::CH * XS;                          // [2][CH]
+  int *rows = reinterpret_cast<int *>(vsum + 2 * G::CH);    // [CH]
+  float *s_mu = reinterpret_cast<float *>(rows + G::CH);    // [2][KP] | s_sig [2][KP]
+  float *s_sig = s_mu + 2 * KP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int E = a.ensemble;
+  const int n_rows = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
+  const int row0 = blockIdx.x * ch_rows;
+  if (row0 >= n_rows) return;
+  const int n_here = min(ch_rows, n_rows - row0), tiles = (n_here + 31) / 32;
+  // ---- the chunk's rows ------------------------------------------------------------------------------------------------
+  for (int i = tid; i < tiles * 32; i += 512) {
+    const int rr = row0 + i;
+    int v = rr < n_rows ? rr : 0;
+    if (a.row_idx) v = a.row_idx[v];
+    rows[i] = rr < n_rows ? v : -1;
+    vsum[i] = 0.0f;
+    vsum[G::CH + i] = 0.0f;
+  }
+  if (tid < 2 * KP) {
+    const int n2 = tid / KP, k = tid - n2 * KP;
+    const CfNet &M = a.net[n2];
+    const int kc = k < a.obs_dim ? k : 0;
+    s_mu[n2 * KP + k] = (M.in_mu && k < a.obs_dim) ? M.in_mu[kc] : 0.0f;
+    s_sig[n2 * KP + k] = (M.in_mu && k < a.obs_dim) ? M.in_sig[kc] : 1.0f;
+  }
+  __syncthreads();
+  for (int base = 0; base < tiles * 32 * KP; base += 512 * 4) {     // four requests in flight per thread
+    float xv[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + 512 * u + tid, b = i / KP, k = i - b * KP;
+      const int rr = i < tiles * 32 * KP ? rows[b] : -1;
+      xv[u] = a.obs[(size_t)(rr >= 0 ? rr : 0) * a.obs_dim + (k < a.obs_dim ? k : 0)];
+      ok[u] = rr >= 0 && k < a.obs_dim;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + 512 * u + tid, b = i / KP, k = i - b * KP;
+      if (i < tiles * 32 * KP) xraw[b * XS + k] = ok[u] ? xv[u] : 0.0f;
+    }
+  }
+  // ---- member after member ---------------------------------------------------------------------------------------------
+  for (int net = 0; net < 2 * E; ++net) {
+    const int ni = net / E, e = net - ni * E;
+    const CfNet &N = a.net[ni];
+    __syncthreads();          // the previous member's fragments are read (and, first time, the rows are staged)
+    {
+      const f16x8 *g0 = N.w0 + (size_t)e * N.w0_stride, *g1 = N.w1 + (size_t)e * N.w1_stride;
+      constexpr int TOT = G::W0Q + G::W1Q;
+      for (int base = 0; base < TOT; base += 512 * 5) {             // 80 KB: five requests in flight per thread
+        f16x8 q[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const int i = base + 512 * u + tid;
+          const int ic = i < TOT ? i : 0;
+          q[u] = ic < G::W0Q ? g0[ic] : g1[ic - G::W0Q];
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const int i = base + 512 * u + tid;
+          if (i < TOT) w0s[i] = q[u];          // (w1s follows w0s)
+        }
+      }
+    }
+    __syncthreads();
+    const float *st = N.stats + (size_t)e * NSTAT;
+    const f16x8 *w0 = w0s + lane, *w1 = w1s + lane;
+    for (int t = wave; t < tiles; t += 8) {
+      const float *xt = xraw + (size_t)t * 32 * XS;
+      // input fragment: this critic's scaler, the row's lift, the split -- in registers
+      float xs[S0][8];
+      float m0 = 0.0f;
+#pragma unroll
+      for (int s = 0; s < S0; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = 16 * s + 8 * hh + j;
+          float x = (xt[r * XS + k] - s_mu[ni * KP + k]) / s_sig[ni * KP + k];   // TensorStandardScaler.transform, utils.py:156
+          if (k >= a.obs_dim) x = 0.0f;
+          xs[s][j] = x;
+          m0 = fmaxf(m0, fabsf(x));
+        }
+      m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));
+      const float t0 = pow2_lift(m0);
+      const float bound1 = (st[1] * m0 + st[2]) * 1.001f, t1 = pow2_lift(bound1);
+      const float inv0 = 1.0f / (st[0] * t0), inv1 = 1.0f / (st[4] * t1);
+      f32x16 acc[NT];
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tt][i] = 0.0f;
+      // layer 0
+#pragma unroll
+      for (int s = 0; s < S0; ++s) {
+        f16x8 b1, b2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          _Float16 c1, c2;
+          split_h(xs[s][j] * t0, c1, c2);
+          b1[j] = c1; b2[j] = c2;
+        }
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          const f16x8 *q = w0 + ((size_t)(tt * S0 + s) * 2) * 64;
+          mm3(acc[tt], q[0], q[64], b1, b2);
+        }
+      }
+      // h1 = swish(. + b0), lifted and split: accumulator registers 8 half .. + 7 of tile tt are slab 2 tt + half of layer 1
+      f16x8 bf[S1][2];
+      {
+        const float *b0 = N.b0 + (size_t)e * HC;
+        u32x4 bu[S1][2];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(b0 + 32 * tt + 8 * q + 4 * hh);
+            Epi4 es;
+            epi_all<false>(es, acc[tt], q, inv0, bv, t1);
+            const int S = 2 * tt + (q >> 1), o = 2 * (q & 1);
+            bu[S][0][o] = es.q1[0]; bu[S][0][o + 1] = es.q1[1];
+            bu[S][1][o] = es.q2[0]; bu[S][1][o + 1] = es.q2[1];
+          }
+#pragma unroll
+        for (int S = 0; S < S1; ++S) { bf[S][0] = __builtin_bit_cast(f16x8, bu[S][0]); bf[S][1] = __builtin_bit_cast(f16x8, bu[S][1]); }
+      }
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tt][i] = 0.0f;
+      // layer 1
+#pragma unroll
+      for (int s = 0; s < S1; ++s) {
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          const f16x8 *q = w1 + ((size_t)(tt * S1 + s) * 2) * 64;
+          mm3(acc[tt], q[0], q[64], bf[s][0], bf[s][1]);
+        }
+      }
+      // h2 = swish(. + b1); output = h2 . W2[:, 0] + b2; output scaler
+      float dot = 0.0f;
+      {
+        const float *b1 = N.b1 + (size_t)e * HC;
+        const float *w2 = N.w2 + (size_t)e * N.w2_stride;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int k0 = 32 * tt + 8 * q + 4 * hh;
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(b1 + k0);
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(w2 + ((size_t)(k0 >> 3) * 64 + ((k0 >> 2) & 1) * 32) * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) dot = __builtin_fmaf(swishf(__builtin_fmaf(acc[tt][4 * q + s], inv1, bv[s])), wv[s], dot);
+          }
+      }
+      dot += __shfl_xor(dot, 32, 64);
+      const float o_sig = N.out_mu ? N.out_sig[0] : 1.0f, o_mu = N.out_mu ? N.out_mu[0] : 0.0f;
+      const float val = o_sig * (dot + N.b2[(size_t)e * 32]) + o_mu;       // inverse_transform, models/pens/utils.py:167
+      if (hh == 0) vsum[ni * G::CH + t * 32 + r] += val;                  // (this wave owns the tile: members in order)
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * tiles * 32; i += 512) {      // mean over ALL members (pe.py:343)
+    const int n2 = i / (tiles * 32), b = i - n2 * (tiles * 32);
+    const int rr = rows[b];
+    if (rr >= 0) a.net[n2].out[rr] = vsum[n2 * G::CH + b] / (float)E;
+  }
+}
+
 // (re)builds the two f16 images and the statistics of a 128-wide single-output ensemble when its packs changed
 int ensure_cf16(cmbpo_mlp *m, hipStream_t s) {
   const int E = m->ensemble;
@@ -255,6 +450,12 @@ extern "C" int cmbpo_critic_pair_predict(cmbpo_mlp_t *v, cmbpo_mlp_t *vc, const 
                                          const int32_t *d_n_rows, int n_rows, float *d_v, float *d_vc, void *stream) {
   return cmbpo_internal_critic_pair_ride(v, vc, d_obs, obs_dim, d_row_idx, d_n_rows, n_rows, d_v, d_vc, nullptr, nullptr, nullptr,
                                          nullptr, nullptr, nullptr, stream);
+}
+
+// rows from which the critics run member after member with LDS-resident weights (critic_big_kernel; no rider there)
+int cmbpo_internal_critic_big_min() {
+  static const int v = getenv("CMBPO_CRITIC_BIG_MIN") ? atoi(getenv("CMBPO_CRITIC_BIG_MIN")) : 24576;
+  return v;
 }
 
 // can the actor ride along? (its f16 kernel applies, same input width, room for one more wave)
@@ -309,6 +510,32 @@ int cmbpo_internal_critic_pair_ride(cmbpo_mlp *v, cmbpo_mlp *vc, const float *d_
     a.pol.obs = d_obs; a.pol.eps = d_eps; a.pol.row_idx = d_row_idx; a.pol.n_rows_dev = d_n_rows; a.pol.n_rows = n_rows;
     a.pol.pi = d_pi; a.pol.logp = d_logp; a.pol.mu = d_mu; a.pol.ls = d_ls;
     a.has_pol = 1;
+  }
+  // large batches without a rider: members one after the other with their weights in LDS (critic_big_kernel)
+  if (!a.has_pol && n_rows >= cmbpo_internal_critic_big_min()) {
+    hipDeviceProp_t prop;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                 ? prop.multiProcessorCount : 256;
+    }
+    auto launch_big = [&](auto geo, auto kern) -> int {
+      using G = decltype(geo);
+      static bool attr = false;
+      if (!attr) {
+        CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+        attr = true;
+      }
+      int ch = (cmbpo_ceil_div(n_rows, n_cu) + 31) / 32 * 32;      // one chunk per CU where the batch allows
+      if (ch > G::CH) ch = G::CH;
+      hipLaunchKernelGGL(kern, dim3(cmbpo_ceil_div(n_rows, ch)), dim3(512), G::LDS, s, a, ch);
+      CMBPO_HIP_CHECK(hipGetLastError());
+      return CMBPO_OK;
+    };
+    if (S0 == 2) return launch_big(BigGeo<2>{}, critic_big_kernel<2>);
+    if (S0 == 3) return launch_big(BigGeo<3>{}, critic_big_kernel<3>);
+    return launch_big(BigGeo<4>{}, critic_big_kernel<4>);
   }
   const int threads = 64 * (2 * v->ensemble + a.has_pol);
   const size_t lds = ((size_t)32 * (16 * S0 + 1) + (size_t)2 * v->ensemble * 32) * sizeof(float);

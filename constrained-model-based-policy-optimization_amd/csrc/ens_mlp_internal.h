@@ -81,6 +81,7 @@ bool cmbpo_internal_policy_f16_eligible(const cmbpo_mlp *m);
 int cmbpo_internal_launch_policy_f16(cmbpo_mlp *m, const MlpKernelArgs &a, hipStream_t s);
 int cmbpo_internal_policy_f16_args(cmbpo_mlp *m, void *pf_args, int *s0_out, hipStream_t s);
 // both critics and, riding along as one more wave per tile, the actor at the same rows (critic_f16.hip)
+int cmbpo_internal_critic_big_min();
 bool cmbpo_internal_critic_pair_can_ride(const cmbpo_mlp *v, const cmbpo_mlp *vc, const cmbpo_mlp *policy);
 int cmbpo_internal_critic_pair_ride(cmbpo_mlp *v, cmbpo_mlp *vc, const float *d_obs, int obs_dim, const int32_t *d_row_idx,
                                     const int32_t *d_n_rows, int n_rows, float *d_v, float *d_vc, cmbpo_mlp *policy,

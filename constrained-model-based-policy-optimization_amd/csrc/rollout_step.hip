@@ -47,7 +47,8 @@ static int step_impl(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy,
     // ... and, where it fits, the actor for the next step as one more wave per tile: both read next_obs, the store above has
     // consumed this step's actions, and nothing below reads them
     static const int ride_max = getenv("CMBPO_RIDE_MAX_ROWS") ? atoi(getenv("CMBPO_RIDE_MAX_ROWS")) : (1 << 30);
-    const bool ride = d_eps_next != nullptr && n_alive <= ride_max && cmbpo_internal_critic_pair_can_ride(v, vc, policy);
+    const bool ride = d_eps_next != nullptr && n_alive <= ride_max && n_alive < cmbpo_internal_critic_big_min() &&
+                      cmbpo_internal_critic_pair_can_ride(v, vc, policy);     // (large batches: the member-after-member kernel)
     if ((rc = cmbpo_internal_critic_pair_ride(v, vc, r->next_obs, r->obs_dim, r->alive_idx, nullptr, n_alive, w(r->v_n), w(r->vc_n),
                                               ride ? policy : nullptr, d_eps_next, w(r->act_t), w(r->logp_t), w(r->mu_t), w(r->ls_t),
                                               stream)))

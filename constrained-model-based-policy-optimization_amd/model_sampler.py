@@ -351,7 +351,10 @@ class ModelSampler:
         min_alive = int(np.floor(min_alive_ratio * self.batch_size + 1e-9)) if min_alive_ratio is not None else 0
         left = int(max_steps) if max_steps is not None else (1 << 30)
         steps, info = 0, None
-        if sharded or env.kernel_events is not None:
+        # shards without a budget or stop rule between them roll independently: the native loop runs each shard to its
+        # end and the counts are exchanged ONCE (one collective per call instead of one per step)
+        local_only = sharded and not max_samples and stop_total is None and min_alive_ratio is None and max_steps is None
+        if (sharded and not local_only) or env.kernel_events is not None:
             while left > 0 and self.any_alive() and pool.has_room:
                 _, _, _, info = self.sample(max_samples=max_samples)
                 steps += 1
@@ -418,6 +421,10 @@ class ModelSampler:
                 info = {"alive_ratio": pool.n_alive / B, "ensemble_dkl_path": t["dkl_t"], "cost": t["cost_t"]}
                 if done < take:       # a stop test fired inside the call
                     break
+        if local_only:
+            g = self.comm.all_reduce_host([pool.n_alive, self.batch_size, self._host["total_samples"]])
+            self.global_alive, self._global_total_samples = int(g[0]), g[2]
+            info = {"alive_ratio": g[0] / g[1], "ensemble_dkl_path": t["dkl_t"], "cost": t["cost_t"]}
         return steps, info
 
     def _idle_step(self, max_samples):

@@ -163,6 +163,7 @@ struct H3Args {
   const f16x8 *w0, *w1, *w2;
   size_t w0_stride, w1_stride, w2_stride;   // per member, in 16-B units
   const float *stats;                        // [E][NSTAT]
+  int item0;                                 // first item of this launch (a launch may carry a suffix of the item list)
 };
 
 // S0: k-slabs of the input layer (in_pad <= 16 S0); OTP: output n-tiles, 2 or 4 (2 out_dim <= 32 OTP); RT: 32-row tiles per item
@@ -234,16 +235,16 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
     const int ob = p.o_tiles * 32;
     b2pre = p.b2[(size_t)e2 * ob + (tid < ob ? tid : 0)];
   };
-  fetch_row(blockIdx.x, threadIdx.x);
+  fetch_row(a.item0 + blockIdx.x, threadIdx.x);
   fetch_x(threadIdx.x);
-  fetch_bias(blockIdx.x, threadIdx.x);
+  fetch_bias(a.item0 + blockIdx.x, threadIdx.x);
 #ifdef CMBPO_STAMPS
   unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = __builtin_amdgcn_s_memtime();
   const unsigned long long t_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-  for (int item = blockIdx.x; item < p.n_items; item += gridDim.x) {
+  for (int item = a.item0 + blockIdx.x; item < p.n_items; item += gridDim.x) {
     // the thread index, re-read inside the loop through an opaque move: everything derived from it is recomputed per
     // item instead of being hoisted out of the loop and parked in scratch (the loop body needs every register)
     int tid = threadIdx.x;
@@ -721,16 +722,20 @@ int cmbpo_internal_launch_h3(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
       if (best < 0 || cost <= best) { best = cost; RT = rts[i]; }
     }
   }
-  const int tiles = cmbpo_ceil_div(a.n_rows, 32 * RT);
-  k.m.tiles = tiles;
-  k.m.n_items = tiles * E;
   const int S0 = m->h3_s0, OTP = m->h3_otp;
-  const size_t lds = (size_t)lds_bytes(S0, RT);
-  CMBPO_REQUIRE(lds <= 160 * 1024, "ens_h3: LDS budget exceeded (%zu B)", lds);
-  const int grid = k.m.n_items < n_cu ? k.m.n_items : n_cu;
   static bool attr_done[5][5][5] = {};
+  // one launch: items [item0, end) of the (member-major) item list at rt 32-row tiles per item; end < 0: all of it
+  auto launch = [&](int rt, int item0, int end) -> int {
+    const int tiles = cmbpo_ceil_div(a.n_rows, 32 * rt);
+    k.m.tiles = tiles;
+    k.m.n_items = end < 0 ? tiles * E : end;     // (the kernel's loop bound)
+    k.item0 = item0;
+    const size_t lds = (size_t)lds_bytes(S0, rt);
+    CMBPO_REQUIRE(lds <= 160 * 1024, "ens_h3: LDS budget exceeded (%zu B)", lds);
+    const int n_here = k.m.n_items - item0;
+    const int grid = n_here < n_cu ? n_here : n_cu;
 #define CMBPO_H3_CASE(S0_, OTP_, RT_)                                                                                  \
-  if (S0 == S0_ && OTP == OTP_ && RT == RT_) {                                                                         \
+  if (S0 == S0_ && OTP == OTP_ && rt == RT_) {                                                                         \
     if (!attr_done[S0_][OTP_][RT_]) {                                                                                  \
       CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ens_h3_kernel<S0_, OTP_, RT_>),               \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(S0_, RT_)));      \
@@ -741,9 +746,25 @@ int cmbpo_internal_launch_h3(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
 #define CMBPO_H3_CASES(RT_)                                                                                            \
   CMBPO_H3_CASE(2, 2, RT_) CMBPO_H3_CASE(3, 2, RT_) CMBPO_H3_CASE(4, 2, RT_)                                           \
   CMBPO_H3_CASE(2, 4, RT_) CMBPO_H3_CASE(3, 4, RT_) CMBPO_H3_CASE(4, 4, RT_)
-  CMBPO_H3_CASES(4) CMBPO_H3_CASES(2) CMBPO_H3_CASES(1)
+    CMBPO_H3_CASES(4) CMBPO_H3_CASES(2) CMBPO_H3_CASES(1)
 #undef CMBPO_H3_CASES
 #undef CMBPO_H3_CASE
-  CMBPO_HIP_CHECK(hipGetLastError());
-  return CMBPO_OK;
+    CMBPO_HIP_CHECK(hipGetLastError());
+    return CMBPO_OK;
+  };
+  // The last round of 128-row items leaves most CUs idle when few items remain (100 000 rows x 7 members = 5474 items on 256
+  // CUs: 21 full rounds + 98 items).  Up to half a round of leftovers goes as 64-row items in a launch of its own: twice the
+  // items, all in one round, each ~0.6 of a 128-row item's time.  An item is (member, row tile) in member-major order in both
+  // lists, so a suffix of one list is a suffix of the other.
+  static const int split_tail = getenv("CMBPO_ENS_H3_SPLIT_TAIL") ? atoi(getenv("CMBPO_ENS_H3_SPLIT_TAIL")) : 1;
+  const int tiles4 = cmbpo_ceil_div(a.n_rows, 128), n4 = tiles4 * E, left = n4 % n_cu;
+  if (RT == 4 && split_tail && g_h3_rt == 0 && n4 >= 2 * n_cu && left > 0 && left <= n_cu / 2) {
+    const int full = n4 - left;
+    const int e0 = full / tiles4, t0 = full - e0 * tiles4;
+    const int tiles2 = cmbpo_ceil_div(a.n_rows, 64);
+    if (int rc = launch(4, 0, full)) return rc;
+    return launch(2, e0 * tiles2 + 2 * t0, -1);
+  }
+  return launch(RT, 0, -1);
 }
+

@@ -77,6 +77,28 @@ def test_ens_forward_f16_item_shapes(hip_lib, rt, task, n):
     assert hip_lib.cmbpo_set_ens_f16_row_tiles(3) < 0
 
 
+def test_ens_forward_tail_round_as_half_items(hip_lib):
+    """35 000 rows x 7 members = 1918 items of 128 rows on 256 CUs: 7 full rounds + 126 left over, which go as 64-row items
+    in a launch of their own (ens_h3.hip).  Every row against the oracle, and bitwise against the same forward with the
+    item size forced (no split)."""
+    _cuda()
+    rng = np.random.default_rng(4242)
+    m, ws, bs, sc_in, sc_out, obs_dim, act_dim = _dyn_model(rng, "AntSafe-v2")
+    n = 35000
+    x = rng.standard_normal((n, obs_dim + act_dim)).astype(np.float32)
+    mean, var = m.predict_ensemble(x)
+    rmean, rvar = refcpu.ens_forward(x, ws, bs, sc_in, sc_out)
+    np.testing.assert_allclose(mean, rmean, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(var, rvar, rtol=2e-3, atol=1e-6)
+    assert hip_lib.cmbpo_set_ens_f16_row_tiles(4) == 0       # forced 128-row items: one launch, no split
+    try:
+        mean4, var4 = m.predict_ensemble(x)
+    finally:
+        hip_lib.cmbpo_set_ens_f16_row_tiles(0)
+    np.testing.assert_array_equal(mean, mean4)
+    np.testing.assert_array_equal(var, var4)
+
+
 def test_ens_forward_no_scalers_hidden128(hip_lib):
     _cuda()
     from cmbpo_amd import synthetic

@@ -422,8 +422,11 @@ class ModelSampler:
                 if done < take:       # a stop test fired inside the call
                     break
         if local_only:
-            g = self.comm.all_reduce_host([pool.n_alive, self.batch_size, self._host["total_samples"]])
-            self.global_alive, self._global_total_samples = int(g[0]), g[2]
+            # (a shard whose buffer is full cannot continue: its rows do not keep the other shards in the caller's loop --
+            # every shard leaves `while any_alive() and has_room` after the same call, the collectives stay matched)
+            g = self.comm.all_reduce_host([pool.n_alive, self.batch_size, self._host["total_samples"],
+                                           pool.n_alive if pool.has_room else 0])
+            self.global_alive, self._global_total_samples = int(g[3]), g[2]
             info = {"alive_ratio": g[0] / g[1], "ensemble_dkl_path": t["dkl_t"], "cost": t["cost_t"]}
         return steps, info
 

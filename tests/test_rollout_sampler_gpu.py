@@ -166,6 +166,7 @@ def test_hip_sampler_matches_oracle_on_fresh_seeds(hip_lib, task, B, T, hidden, 
     ("AntSafe-v2", 1000, 12, "uncertainty", 2.5, 9000, None, None),     # small-batch path (one-workgroup bookkeeping), budget
     ("AntSafe-v2", 1000, 12, "schedule", None, None, 0.5, 0.1),         # stop on total_samples / alive ratio (cmbpo.py:356-359)
     ("HalfCheetahSafe-v2", 6000, 7, "uncertainty", 2.5, None, None, 0.1),  # > 4096 rows: separate bookkeeping calls + compaction
+    ("HalfCheetahSafe-v2", 26000, 4, "schedule", None, None, None, None),  # >= 24576 rows: the critics' member-after-member kernel, the actor its last member
 ])
 def test_sample_many_equals_a_loop_of_sample(hip_lib, task, B, T, mode, lim_scale, budget, stop_frac, min_ratio):
     """cmbpo_rollout_run (ModelSampler.sample_many) takes exactly the steps a Python loop of sample() takes: same

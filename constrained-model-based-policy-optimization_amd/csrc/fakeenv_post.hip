@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kThreads) void fakeenv_post_kernel(const PostArgs p
         // var = exp(2 log_std).  Inside the clip range that is log_std = 0.5 log(var) and exp(2 log_std) = var up to
         // rounding (the KL is compared at 1e-4, not bit for bit): one log instead of sqrt + log + exp per member.
         const float v0 = p.var[e * mstride + base];
-        float l = __fmul_rn(0.5f, logf(v0));
+        float l = __fmul_rn(0.5f, __logf(v0));              // (v_log_f32: the KL is compared at 1e-4; libm's logf is ~25 instructions)
         const bool inside = l >= -100.0f && l <= 1e8f;       // false for NaN as well
         if (!inside) l = clip_np(logf(sqrtf(v0)), -100.0f, 1e8f);   // np.clip: a NaN stays a NaN
         ls[e] = l;

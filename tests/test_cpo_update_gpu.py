@@ -127,6 +127,34 @@ def test_fvp_wide_range_direction_agrees_between_the_matrix_paths(hip_lib, pi_pa
     _close(got, graph.fisher_vp(params, v, 0.1), msg="wide-range direction")
 
 
+def test_fvp_and_gradient_are_additive_over_the_batch_at_a_million_samples(hip_lib):
+    """Size-independent property at a batch the oracle cannot take: raw sums over a batch equal the sums over its two
+    (unequal, tile-misaligned) parts -- every tile, the ragged last one and the per-workgroup partial vectors included."""
+    _need_gpu()
+    from worlds import make_update_batch
+    from cmbpo_amd.cpo_update import PolicyOps
+    D, A, n, cut = 29, 8, 1_000_003, 345_679
+    rng = np.random.default_rng(11)
+    params, batch = make_update_batch(rng, n, D, A, 128, 0.3, 1.0, 35)
+    v = rng.standard_normal(params.shape).astype(np.float32)
+    keys = ("obs", "act", "adv", "cadv", "logp_old", "cost", "mu_old", "log_std_old")
+
+    def run(lo, hi):
+        ops = PolicyOps(D, A, 128, device="cuda:0")
+        ops.set_params(params)
+        ops.bind(*[batch[k][lo:hi] for k in keys])
+        g, s = ops.loss_grad(0)
+        hv = ops.fvp(v)
+        return g.astype(np.float64) * (hi - lo), hv.astype(np.float64) * (hi - lo), s
+
+    g_all, h_all, s_all = run(0, n)
+    g_a, h_a, s_a = run(0, cut)
+    g_b, h_b, s_b = run(cut, n)
+    for name, whole, parts in (("gradient", g_all, g_a + g_b), ("fvp", h_all, h_a + h_b)):
+        np.testing.assert_allclose(whole, parts, rtol=2e-4, atol=2e-5 * float(np.abs(whole).max()), err_msg=name)
+    np.testing.assert_allclose(s_all[:5], (s_a + s_b)[:5], rtol=1e-9)
+
+
 SCENARIOS = [   # name, cost_p, cadv_scale, cost_lim, constrained, real_cost, seed
     ("feasible", 0.05, 1.0, 10.0, True, 3.0, 11),
     ("violating", 0.9, 1.0, 10.0, True, 25.0, 12),

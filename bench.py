@@ -54,9 +54,14 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def spawn_ranks(args, argv):
-    """Launcher half of ``python bench.py --gpus N``: N rank processes of this same script, one per GPU."""
+def spawn_ranks(args, argv, deadline_s=900.0):
+    """Launcher half of ``python bench.py --gpus N``: N rank processes of this same script, one per GPU.  All children
+    are watched from launch time on: the first one to exit non-zero (or the deadline) ends the job -- the others are
+    terminated, never left waiting in a rendezvous or a collective for a rank that is gone."""
+    import threading
+    t_launch = time.time()
     s = socket.socket()
+    s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
@@ -67,22 +72,46 @@ def spawn_ranks(args, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if rank == 0 else sys.stderr, text=(rank == 0)))
-    line = None
-    for out in procs[0].stdout:          # rank 0 prints the one JSON line; anything else it prints is passed on
-        out = out.rstrip("\n")
-        if out.startswith("{") and '"metric"' in out:
-            line = out
-        else:
-            print(out, file=sys.stderr, flush=True)
-    rc = 0
-    deadline = time.time() + 600
-    for p in procs:
-        try:
-            code = p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()                     # the exact process we started
-            code = p.wait()
-        rc = rc or code
+    result = []
+
+    def relay():                         # rank 0 prints the one JSON line; anything else it prints is passed on
+        for out in procs[0].stdout:
+            out = out.rstrip("\n")
+            if out.startswith("{") and '"metric"' in out:
+                result.append(out)
+            else:
+                print(out, file=sys.stderr, flush=True)
+
+    reader = threading.Thread(target=relay, daemon=True)
+    reader.start()
+    rc, failed = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(k, c) for k, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed, rc = bad[0]
+            print(f"bench.py launcher: rank {failed} exited with code {rc}; stopping the other ranks", file=sys.stderr)
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() - t_launch > deadline_s:
+            print(f"bench.py launcher: no result after {deadline_s:.0f} s; stopping all ranks", file=sys.stderr)
+            rc = 124
+            break
+        time.sleep(0.05)
+    if rc != 0:
+        for p in procs:                  # the exact processes we started
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=5)
+    line = result[-1] if result else None
     if rc == 0 and line is None:
         print("bench.py launcher: rank 0 printed no result line", file=sys.stderr)
         rc = 1
@@ -436,6 +465,8 @@ def dry_run(args):
     """Launcher / rendezvous check without a GPU: every rank joins, one all-reduce, rank 0 prints the line."""
     import cmbpo_amd  # noqa: F401
     from cmbpo_amd.dist import Comm
+    if os.environ.get("CMBPO_BENCH_TEST_FAIL_RANK") == os.environ.get("RANK", "0"):
+        sys.exit(7)                      # launcher test: a rank that dies before the rendezvous
     comm = Comm.init_from_env(None if torch.cuda.is_available() else "gloo")
     seen = torch.zeros(max(comm.world, 1), dtype=torch.float64)
     seen[comm.rank] = 1.0

@@ -227,7 +227,7 @@ class CMBPO:
                     self.model_sampler.sample_many(max_samples=int(self.approx_model_batch - samples_added),
                                                    stop_total=.99 * self.approx_model_batch - samples_added,
                                                    min_alive_ratio=0.1)
-                    if self.model_sampler._total_samples + samples_added >= .99 * self.approx_model_batch:
+                    if self.model_sampler.global_total_samples + samples_added >= .99 * self.approx_model_batch:
                         keep_rolling = False
                     rollout_diagnostics = self.model_sampler.finish_all_paths()
                     model_samples_new, buffer_diagnostics_new = self.model_buf.get(as_tensors=True)

@@ -8,6 +8,10 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+
+#include <atomic>
+#include <mutex>
 
 int cmbpo_internal_book_post_mirror(const cmbpo_rollout_t *r, int n_alive, uint32_t *d_host_out, uint32_t seq, void *stream);
 int cmbpo_internal_scalars_mirror(const cmbpo_rollout_t *r, uint32_t *d_host_out, uint32_t seq, void *stream);
@@ -79,46 +83,66 @@ extern "C" int cmbpo_rollout_step(const cmbpo_rollout_t *r, int n_alive, cmbpo_m
 // alive lists and the cur / next arrays, advance the column) without leaving native code -- at 1e3 branches a step is
 // ~85 us of kernels and the interpreter between two steps was a quarter of it.  *r is updated in place exactly as the
 // per-step caller would leave it.  Stops after max_steps, when no branch is alive, when at most min_alive are (the
-// reference's `alive_ratio <= 0.1`, algorithms/cmbpo.py:358-359), when total_samples reaches stop_total (>= 0; :356-357)
+// reference's `alive_ratio <= 0.1`, algorithms/cmbpo.py:358-359), when total_samples reaches stop_total (NaN: no such test; :356-357)
 // or when the buffer is full.  d_eps / d_elite: the draws of the first step, one step further every eps_stride /
 // elite_stride elements.  h_scalars: [max_steps][384 B] (pinned), the counters of every step taken.
 // Host-mapped mirror of a step's counters (one 512-byte slot per step of a call): the single-workgroup bookkeeping kernel that
 // ends a small-batch step writes them there and raises a sequence word; the host polls it.  NULL if the mapping cannot be had
 // (the copy + stream synchronisation of cmbpo_rollout_read_scalars is used instead).
 namespace {
+constexpr int kMirrorSlots = 64, kMirrorDwords = 128, kMaxDevices = 64;
+// one mirror per device (the device pointer of a mapping belongs to the device that was current when it was taken);
+// the sequence word of a slot only has to differ from the slot's previous one: one process-wide atomic counter
 struct Mirror {
   uint32_t *h = nullptr, *d = nullptr;
   bool tried = false;
 };
-Mirror g_mirror;
-uint32_t g_seq = 0;
-constexpr int kMirrorSlots = 64, kMirrorDwords = 128;
+Mirror g_mirror[kMaxDevices];
+std::mutex g_mirror_mu;
+std::atomic<uint32_t> g_seq{0};
+
+uint32_t next_seq() {
+  uint32_t s = g_seq.fetch_add(1, std::memory_order_relaxed) + 1;
+  return s ? s : g_seq.fetch_add(1, std::memory_order_relaxed) + 1;      // never 0
+}
 
 Mirror &mirror() {
-  if (!g_mirror.tried) {
-    g_mirror.tried = true;
+  static Mirror none;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return none;
+  std::lock_guard<std::mutex> lock(g_mirror_mu);
+  Mirror &m = g_mirror[dev];
+  if (!m.tried) {
+    m.tried = true;
     const char *e = getenv("CMBPO_STEP_MIRROR");
-    if (e && e[0] == '0') return g_mirror;
+    if (e && e[0] == '0') return m;
     void *h = nullptr, *d = nullptr;
     if (hipHostMalloc(&h, (size_t)kMirrorSlots * kMirrorDwords * 4, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) == hipSuccess &&
         hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
       memset(h, 0, (size_t)kMirrorSlots * kMirrorDwords * 4);
-      g_mirror.h = static_cast<uint32_t *>(h);
-      g_mirror.d = static_cast<uint32_t *>(d);
+      m.h = static_cast<uint32_t *>(h);
+      m.d = static_cast<uint32_t *>(d);
     } else {
       (void)hipGetLastError();
       if (h) (void)hipHostFree(h);
     }
   }
-  return g_mirror;
+  return m;
 }
 
-// wait until the kernel raised `seq` in the slot; after ~2 s fall back to a stream synchronisation
+// wait until the kernel raised `seq` in the slot; after 2 s of wall clock fall back to a stream synchronisation
 int wait_mirror(const uint32_t *slot, uint32_t seq, hipStream_t s) {
   const volatile uint32_t *flag = slot + 96;
-  for (long spin = 0; spin < 400000000L; ++spin) {
-    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return CMBPO_OK;
-    __builtin_ia32_pause();
+  timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (;;) {
+    for (int spin = 0; spin < 4096; ++spin) {
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return CMBPO_OK;
+      __builtin_ia32_pause();
+    }
+    timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > 2.0) break;
   }
   CMBPO_HIP_CHECK(hipStreamSynchronize(s));
   if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return CMBPO_OK;
@@ -142,7 +166,7 @@ extern "C" int cmbpo_rollout_run(cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *p
     bool next_ready = false;
     Mirror &mir = mirror();
     const int slot = done % kMirrorSlots;
-    const uint32_t seq = ++g_seq ? g_seq : ++g_seq;      // never 0
+    const uint32_t seq = next_seq();
     uint32_t *d_slot = mir.d ? mir.d + (size_t)slot * kMirrorDwords : nullptr;
     int rc = step_impl(r, n_alive, policy, model, v, vc, task, ensemble, d_eps + (size_t)done * eps_stride,
                        d_elite + (size_t)done * elite_stride, d_mean, d_var, ready, eps_next, &next_ready, d_slot, seq, stream);
@@ -181,7 +205,7 @@ extern "C" int cmbpo_rollout_run(cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *p
     r->ptr += 1;
     ++done;
     if (n_alive <= min_alive) break;
-    if (stop_total >= 0.0 && dsc[CMBPO_D_TOTAL_SAMPLES] >= stop_total) break;
+    if (stop_total == stop_total && dsc[CMBPO_D_TOTAL_SAMPLES] >= stop_total) break;     // NaN: no such test
   }
   *steps_done = done;
   *n_alive_out = n_alive;

@@ -88,6 +88,14 @@ class ModelSampler:
         return self._host["total_samples"]
 
     @property
+    def global_total_samples(self):
+        """`_total_samples` summed over the shards (== `_total_samples` on one GPU): what a stop rule on the job's sample
+        count has to read (algorithms/cmbpo.py:356-357)."""
+        if self.comm is not None and self.comm.world > 1:
+            return getattr(self, "_global_total_samples", 0.0)
+        return self._host["total_samples"]
+
+    @property
     def _total_dkl(self):
         return self._host["total_dkl"]
 
@@ -155,6 +163,7 @@ class ModelSampler:
             self._critics("cur_obs", "v_t", "vc_t", self.batch_size)
         self._n_episodes = 0
         self.global_alive = 1
+        self._global_total_samples = 0.0
         self._host = dict(total_samples=0.0, total_dkl=0.0)
         elites = np.asarray(self.env._model.elite_inds, dtype=np.int32)
         self._elites = torch.as_tensor(elites, device=self.device)
@@ -359,7 +368,9 @@ class ModelSampler:
                 _, _, _, info = self.sample(max_samples=max_samples)
                 steps += 1
                 left -= 1
-                if stop_total is not None and self._total_samples >= stop_total:
+                # every quantity of the stop tests is GLOBAL on a sharded sampler (the budget and alive_ratio already are):
+                # all ranks leave the loop after the same step, so the step's collectives stay matched
+                if stop_total is not None and self.global_total_samples >= stop_total:
                     break
                 if min_alive_ratio is not None and info["alive_ratio"] <= min_alive_ratio:
                     break
@@ -385,7 +396,7 @@ class ModelSampler:
             rs.max_path_length = self._max_path_length
             rs.use_host_budget = 0
             stream = _lib.current_stream()
-            stop = -1.0 if stop_total is None else float(stop_total)
+            stop = float("nan") if stop_total is None else float(stop_total)     # NaN: no stop rule on the total
             done_o, alive_o, swaps_o = self._run_out
             while left > 0 and pool.n_alive > 0 and pool.has_room:
                 ck = self._draws

@@ -299,7 +299,8 @@ int cmbpo_rollout_step(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *polic
 /* Several steps in one call (single-rank path; replaces the body of the rollout loop of algorithms/cmbpo.py:352-360
  * around ModelSampler.sample): step -> counters -> swap of the alive lists and of the cur / next arrays, repeated
  * until max_steps, no branch alive, at most min_alive alive (`alive_ratio <= 0.1`), total_samples >= stop_total
- * (stop_total < 0: no such test) or a full buffer.  *r is left as the caller of cmbpo_rollout_step would leave it.
+ * (stop_total = NaN: no such test; a threshold <= 0 is reached by the first step, as in the reference's
+ * `_total_samples + samples_added >= .99 * approx_model_batch`) or a full buffer.  *r is left as the caller of cmbpo_rollout_step would leave it.
  * d_eps / d_elite: the draws of the first step; step k reads them k * eps_stride / k * elite_stride elements on.
  * h_scalars: [max_steps][384 bytes] of host memory (pinned), the counters of every step taken (iscal | dscal);
  * *list_swaps = how often alive_idx / alive_idx_out changed places. */

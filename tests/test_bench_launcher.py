@@ -26,6 +26,17 @@ def test_gpus2_spawns_two_ranks_and_reports_them():
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 3 and out["warmup"] == 1
 
 
+def test_a_rank_that_dies_at_start_up_ends_the_job():
+    # rank 1 exits before the rendezvous: the launcher reports it and stops rank 0 instead of waiting for torch's
+    # rendezvous timeout
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--dry-run"], {"CMBPO_DIST_BACKEND": "gloo", "CMBPO_BENCH_TEST_FAIL_RANK": "1"})
+    assert r.returncode == 7, (r.returncode, r.stderr[-2000:])
+    assert "rank 1 exited with code 7" in r.stderr
+    assert time.time() - t0 < 120
+
+
 def test_world_mismatch_is_an_error_not_a_silent_one_rank_run():
     # a torchrun-style environment with fewer ranks than --gpus asks for must not fall back to that many ranks
     r = _run(["--gpus", "4", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, drop=())

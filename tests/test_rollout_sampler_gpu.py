@@ -30,7 +30,7 @@ class _Space:
         self.shape = (d,)
 
 
-def hip_world(w, task, T, mode, dkl_lim, B, hidden):
+def hip_world(w, task, T, mode, dkl_lim, B, hidden, comm=None):
     from cmbpo_amd.cpo_policy import CPOPolicy
     from cmbpo_amd.fake_env import FakeEnv
     from cmbpo_amd.model_sampler import ModelSampler
@@ -44,7 +44,7 @@ def hip_world(w, task, T, mode, dkl_lim, B, hidden):
     model.set_elites(w["elites"])
     policy = CPOPolicy(_Space(D), _Space(A), a_hidden_layer_sizes=(128, 128), vf_hidden_layer_sizes=(128, 128),
                        vf_ensemble_size=3, vf_elites=2, vf_activation="swish", vf_loss="MSE", device="cuda:0",
-                       cost_gamma=0.97, cost_lam=0.5, lam=0.95)
+                       cost_gamma=0.97, cost_lam=0.5, lam=0.95, comm=comm)
     policy.actor.set_params(w["pol"])
     policy.v.set_weights(*w["v"])
     policy.vc.set_weights(*w["vc"])
@@ -53,9 +53,9 @@ def hip_world(w, task, T, mode, dkl_lim, B, hidden):
         observation_space, action_space = _Space(D), _Space(A)
 
     env = FakeEnv(_Env(), task, model, predicts_delta=True, predicts_rew=True, predicts_cost=False)
-    pool = ModelBuffer(B, D, A, T, device="cuda:0")
+    pool = ModelBuffer(B, D, A, T, device="cuda:0", comm=comm)
     pool.initialize(policy.pi_info_shapes, gamma=0.99, lam=0.95, cost_gamma=0.97, cost_lam=0.5)
-    sampler = ModelSampler(max_path_length=T, batch_size=B, rollout_mode=mode)
+    sampler = ModelSampler(max_path_length=T, batch_size=B, rollout_mode=mode, comm=comm)
     sampler.initialize(env, policy, pool)
     sampler.set_rollout_dkl(dkl_lim)
     return sampler, pool
@@ -165,6 +165,7 @@ def test_hip_sampler_matches_oracle_on_fresh_seeds(hip_lib, task, B, T, hidden, 
 @pytest.mark.parametrize("task,B,T,mode,lim_scale,budget,stop_frac,min_ratio", [
     ("AntSafe-v2", 1000, 12, "uncertainty", 2.5, 9000, None, None),     # small-batch path (one-workgroup bookkeeping), budget
     ("AntSafe-v2", 1000, 12, "schedule", None, None, 0.5, 0.1),         # stop on total_samples / alive ratio (cmbpo.py:356-359)
+    ("AntSafe-v2", 1000, 12, "schedule", None, None, -0.01, None),      # a threshold <= 0 is reached by the first step (as in the reference)
     ("HalfCheetahSafe-v2", 6000, 7, "uncertainty", 2.5, None, None, 0.1),  # > 4096 rows: separate bookkeeping calls + compaction
     ("HalfCheetahSafe-v2", 26000, 4, "schedule", None, None, None, None),  # >= 24576 rows: the critics' member-after-member kernel, the actor its last member
 ])
@@ -205,7 +206,7 @@ def test_sample_many_equals_a_loop_of_sample(hip_lib, task, B, T, mode, lim_scal
         res, _ = pool.get()
         out.append((state, diag["msampler/samples_added"], res))
     assert out[0][0] == out[1][0], (out[0][0], out[1][0])
-    assert out[0][0][0] >= 2
+    assert out[0][0][0] == 1 if (stop_frac is not None and stop_frac <= 0) else out[0][0][0] >= 2
     assert out[0][1] == out[1][1]
     for k, a, b in zip(NAMES, out[0][2], out[1][2]):
         np.testing.assert_array_equal(a, b, err_msg=k)

@@ -35,6 +35,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+BIND_DKL_SCALE = 4.0            # budget-binding sub-results: DKL limit = 4 x the 5-step calibration: ~40 % of the branches die of uncertainty, the rest live until the budget binds (tools/probe_budget.py)
+BIND_BUDGET_FRAC = 0.5          # ... and max_samples = 0.5 * B * T: binds at step ~19
+
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
@@ -46,6 +49,12 @@ def parse_args(argv=None):
     ap.add_argument("--task", default="AntSafe-v2")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--maxroll", type=int, default=35, help="max_path_length of the rollout (stored steps = maxroll - 1)")
+    ap.add_argument("--rollout-mode", choices=("schedule", "uncertainty"), default="schedule",
+                    help="'uncertainty': branches end when their accumulated ensemble DKL passes --dkl-scale x the calibrated limit")
+    ap.add_argument("--dkl-scale", type=float, default=BIND_DKL_SCALE)
+    ap.add_argument("--budget-frac", type=float, default=0.0,
+                    help="> 0: every sample() gets max_samples = frac * (the job's branches) * (maxroll - 1), the early-termination "
+                         "rule of samplers/model_sampler.py:282-287 (sharded: the cross-rank budget plan, one all-gather per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline rollout only (no update / training / sub-configs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -176,7 +185,7 @@ def build_hip(w, task, B, device, comm=None, maxroll=MAXROLL, mode="schedule"):
     model.set_elites(w["elites"])
     policy = CPOPolicy(_Space(D), _Space(A), a_hidden_layer_sizes=(128, 128), vf_hidden_layer_sizes=(128, 128),
                        vf_ensemble_size=3, vf_elites=2, vf_activation="swish", vf_loss="MSE", device=device,
-                       cost_gamma=0.97, cost_lam=0.5, lam=0.95)
+                       cost_gamma=0.97, cost_lam=0.5, lam=0.95, max_path_length=maxroll)
     policy.actor.set_params(w["pol"])
     policy.v.set_weights(*w["v"])
     policy.vc.set_weights(*w["vc"])
@@ -253,8 +262,11 @@ def get_roofline(w, get_events):
             "samples": float(np.mean(n))}
 
 
-def run_config(name, task, B, maxroll, mode, device, reps=3, dkl_scale=0.6, budget_frac=0.75, seed=0):
-    """One sub-result of the bench line: a shipped configuration's rollout phase on this rank (no collectives)."""
+def run_config(name, task, B, maxroll, mode, device, reps=3, dkl_scale=0.6, budget_frac=0.75, seed=0, budget_binds=False):
+    """One sub-result of the bench line: a shipped configuration's rollout phase on this rank (no collectives).
+    budget_binds: the entry is only valid if the phase ends BECAUSE `max_samples` bound (the shipped configurations stop
+    their rollouts at the model batch, algorithms/cmbpo.py:254-263): >= 12 steps, samples >= 0.99 * max_samples and
+    branches ended by the early-termination rule of samplers/model_sampler.py:282-287 -- anything else is a bench error."""
     from cmbpo_amd import synthetic
     w = build_world(seed, task)
     sampler, pool, env, policy = build_hip(w, task, B, device, None, maxroll, mode)
@@ -282,26 +294,54 @@ def run_config(name, task, B, maxroll, mode, device, reps=3, dkl_scale=0.6, budg
     rollout_phase(sampler, pool, start, max_samples)
     torch.cuda.synchronize()
     n_steps = sampler._n_episodes
+    n_budget = int(sampler.n_budget_terminated)
     out = {"name": name, "task": task, "branches": B, "maxroll": maxroll, "rollout_mode": mode,
            "value": samples / dt, "unit": "imagined env-steps/s", "ms_per_phase": dt / reps * 1e3,
            "samples_per_phase": samples / reps, "steps_per_phase": n_steps,
            "us_per_step": dt / reps / max(n_steps, 1) * 1e6,
            "roofline": ens_roofline(w, env.kernel_events), "gae_get": get_roofline(w, pool.get_events)}
     if mode == "uncertainty":
-        out.update(dkl_lim=lim, max_samples=max_samples)
+        out.update(dkl_lim=lim, max_samples=max_samples, dkl_scale=dkl_scale, budget_frac=budget_frac,
+                   n_budget_terminated=n_budget,
+                   ended_by="budget (max_samples bound)" if n_budget > 0 else "uncertainty (every branch passed the DKL limit)")
+        if budget_binds:
+            ok = n_steps >= 12 and n_budget > 0 and out["samples_per_phase"] >= 0.99 * max_samples
+            if not ok:
+                raise RuntimeError(f"bench.py: {name}: the sample budget did not bind "
+                                   f"(steps {n_steps}, samples {out['samples_per_phase']:.0f} of {max_samples}, "
+                                   f"{n_budget} budget-terminated branches)")
     env.kernel_events, pool.get_events = None, None
     del sampler, pool, env, policy
     torch.cuda.empty_cache()
     return out
 
 
-def time_update(policy, res, n, reps=3):
-    """CPOPolicy.update_policy on the first n samples of a get() list (device tensors); median ms."""
+def constrained_batch(res, seed=11):
+    """SURVEY 8d M1's update batch: the rollout's own (obs, act, logp, mu, log_std) with adv, cadv ~ N(0, 1) and
+    cost ~ Bernoulli(0.05) -- a non-zero cost gradient, so the update takes the reference's full path (two CG solves +
+    two more products, policies/cpo_policy.py:210-224) instead of the TRPO short cut (:216-219)."""
+    gen = torch.Generator(device=res[0].device)
+    gen.manual_seed(seed)
+    n = res[0].shape[0]
+    buf = list(res)
+    buf[2] = torch.randn(n, generator=gen, device=res[0].device)
+    buf[3] = torch.randn(n, generator=gen, device=res[0].device)
+    buf[9] = (torch.rand(n, generator=gen, device=res[0].device) < 0.05).float()
+    return buf
+
+
+def time_update(policy, res, n, reps=3, cost_lim=None):
+    """CPOPolicy.update_policy on the first n samples of a get() list (device tensors); median ms.  cost_lim: the limit
+    of this update (the learned margin starts at 0 every repetition, real-cost history = the limit)."""
     buf = [x[:n].contiguous() for x in res]
     p0 = policy.actor.get_flat_params()
     times, info = [], None
+    keep = policy.cost_lim, policy.real_c_buffer
+    if cost_lim is not None:
+        policy.cost_lim, policy.real_c_buffer = float(cost_lim), [float(cost_lim)] * 300
     for _ in range(reps + 1):
         policy.set_params(p0)
+        policy.agent.margin = 0
         policy.ops.n_fvp = 0
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -309,6 +349,7 @@ def time_update(policy, res, n, reps=3):
         torch.cuda.synchronize()
         times.append((time.perf_counter() - t0) * 1e3)
     policy.set_params(p0)
+    policy.cost_lim, policy.real_c_buffer = keep
     info = dict(info, n_fvp=policy.ops.n_fvp)
     return float(np.median(times[1:])), info
 
@@ -368,16 +409,16 @@ def cpu_train_baseline(E, I, H, O, loss, batch):
     return (time.perf_counter() - t0) / 2 * 1e6
 
 
-def cpu_update_baseline(w, res, n):
+def cpu_update_baseline(w, res, n, cost_lim=10.0, maxroll=MAXROLL):
     """One CPO update of the oracle (torch-CPU autograd graph + update_pi) on n samples; ms."""
     from oracle import refupdate
     host = [x[:n].cpu().numpy() if hasattr(x, "cpu") else np.asarray(x[:n]) for x in res]
     obs, act, adv, cadv, _, _, logp, _, _, cost, ls, mu = host
     D, A = w["obs_dim"], w["act_dim"]
     graph = refupdate.PolicyGraph(D, A, dict(obs=obs, act=act, adv=adv, cadv=cadv, logp_old=logp, cost=cost,
-                                             mu_old=mu, log_std_old=ls), max_path_length=MAXROLL)
+                                             mu_old=mu, log_std_old=ls), max_path_length=maxroll)
     params = np.concatenate([p.reshape(-1) for p in w["pol"]]).astype(np.float32)
-    agent = refupdate.AgentState(MAXROLL, constrained=True)
+    agent = refupdate.AgentState(maxroll, constrained=True)
 
     def grads():
         g, b, lo, sc = graph.grads(params)
@@ -387,7 +428,7 @@ def cpu_update_baseline(w, res, n):
     with np.errstate(all="ignore"):
         refupdate.update_pi(agent, dict(grads=grads, Hx=lambda v: graph.hvp(params, v, 0.1),
                                         set_and_eval=lambda p: graph.evals(np.asarray(p, np.float32))),
-                            params, 0.01, 10.0, [10.0] * 300)
+                            params, 0.01, cost_lim, [cost_lim] * 300)
     return (time.perf_counter() - t0) * 1e3
 
 
@@ -518,24 +559,36 @@ def main():
         B = args.branches
         start = torch.from_numpy(synthetic.start_states(np.random.default_rng(100 + rank), B, task)).to(device)
     w = build_world(0, task)
-    sampler, pool, env, policy = build_hip(w, task, B, device, comm if world > 1 else None, maxroll)
+    sampler, pool, env, policy = build_hip(w, task, B, device, comm if world > 1 else None, maxroll, args.rollout_mode)
+    max_samples, dkl_lim = None, None
+    branches_total = args.branches if args.scaling == "strong" else B * world
+    if args.rollout_mode == "uncertainty":
+        # one limit for the whole job: the mean of the ranks' calibrations (algorithms/cmbpo.py:197-199)
+        sampler.reset(start)
+        lim = float(sampler.compute_dynamics_dkl(start[: min(B, 5000)], depth=5))
+        dkl_lim = float(comm.all_reduce_host([lim])[0]) / world * args.dkl_scale
+        sampler.set_rollout_dkl(dkl_lim)
+    if args.budget_frac > 0:
+        max_samples = int(args.budget_frac * branches_total * (maxroll - 1))
 
     for _ in range(args.warmup):
-        rollout_phase(sampler, pool, start)
+        rollout_phase(sampler, pool, start, max_samples)
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    samples = 0
+    samples, n_budget, n_steps = 0, 0, 0
     for _ in range(args.steps):
-        n, _ = rollout_phase(sampler, pool, start)
+        n, _ = rollout_phase(sampler, pool, start, max_samples)
         samples += n
+        n_budget += int(sampler.n_budget_terminated)
+        n_steps += int(sampler._n_episodes)
     torch.cuda.synchronize()
     comm.barrier()
     dt = time.perf_counter() - t0
     # one more phase with HIP events around the dominant kernel and get()'s kernels (events need the step as separate
     # calls: the timed phases above run it as the single call the sampler makes by default)
     env.kernel_events, pool.get_events = [], []
-    rollout_phase(sampler, pool, start)
+    rollout_phase(sampler, pool, start, max_samples)
     torch.cuda.synchronize()
     events, env.kernel_events = env.kernel_events, None
     get_events, pool.get_events = pool.get_events, None
@@ -543,7 +596,7 @@ def main():
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     comm.all_reduce_max(t)
     dt_max = float(t.item())
-    tot = comm.all_reduce_host([samples])[0]
+    tot, n_budget = comm.all_reduce_host([samples, n_budget])
 
     extras = not args.no_extras
     upd, train, subs = None, None, []
@@ -553,13 +606,34 @@ def main():
         _, res = rollout_phase(sampler, pool, start)
         n_full = int(res[0].shape[0])
         n50 = min(50000, n_full)
-        upd_ms_50k, upd_info = time_update(policy, res, n50)
-        upd_ms_full, _ = time_update(policy, res, n_full, reps=2)
         from cmbpo_amd import _lib as _l
-        upd = {"unit": "ms", "n_50k": n50, "ms_50k": upd_ms_50k, "n_full": n_full, "ms_full": upd_ms_full,
-               "optim_case": int(upd_info["OptimCase"]), "hvps": int(upd_info["n_fvp"]), "per_rank": True,
-               "fvp_ms_full": time_fvp(policy),
+        # (a) the constrained update the north star names: 22 Hessian-vector products (cg(Hx, g), Hx(v), cg(Hx, b), Hx(w),
+        #     policies/cpo_policy.py:210-224) on SURVEY M1's batch; cost_lim just above the batch's mean episode cost
+        #     (c < 0: optim case 2 or 3); (b) the same update on the rollout's own samples, whose costs are all zero:
+        #     the reference's TRPO short cut (:216-219), 11 products
+        cbuf = constrained_batch(res)
+        c_lim = float(cbuf[9].mean()) * policy.max_path_length + 0.5
+        upd = {"unit": "ms", "n_50k": n50, "n_full": n_full, "per_rank": True,
                "matrix_path": "3 x v_mfma_f32_32x32x16_f16 per f32 product" if _l.lib().cmbpo_get_pi_matrix_path() else "fp32 MFMA"}
+        for tag, b_, lim_, want in (("constrained", cbuf, c_lim, 22), ("unconstrained", res, None, 11)):
+            ms50, info50 = time_update(policy, b_, n50, cost_lim=lim_)
+            msfull, infofull = time_update(policy, b_, n_full, reps=2, cost_lim=lim_)
+            ent = {"ms_50k": ms50, "ms_full": msfull, "hvps": int(infofull["n_fvp"]), "hvps_50k": int(info50["n_fvp"]),
+                   "optim_case": int(infofull["OptimCase"]), "optim_case_50k": int(info50["OptimCase"]),
+                   "backtrack_iters": int(infofull["BacktrackIters"]), "accepted": bool(infofull["accepted"]),
+                   "fvp_ms_full": time_fvp(policy)}
+            if tag == "constrained":
+                ent["cost_lim"] = lim_
+                ent["batch"] = "rollout (obs, act, logp, mu, log_std); adv, cadv ~ N(0,1); cost ~ Bernoulli(0.05) (SURVEY 8d M1)"
+                if ent["hvps"] != want or ent["hvps_50k"] != want:
+                    raise RuntimeError(f"bench.py: the constrained update ran {ent['hvps']} / {ent['hvps_50k']} Hessian-vector "
+                                       f"products, not {want} (optim case {ent['optim_case']})")
+            upd[tag] = ent
+        # Metric B = the constrained update
+        upd.update(ms_50k=upd["constrained"]["ms_50k"], ms_full=upd["constrained"]["ms_full"], hvps=upd["constrained"]["hvps"],
+                   optim_case=upd["constrained"]["optim_case"], fvp_ms_full=upd["constrained"]["fvp_ms_full"])
+        cbuf_host = [x[:n50].cpu() for x in cbuf]     # for the CPU update baseline (the same constrained batch)
+        del cbuf
         # Metric C: ensemble training steps (dynamics model on (obs, act) -> (d_obs, rew); critic on obs -> ret)
         obs_t, act_t, ret_t = res[0], res[1], res[4]
         n_tr = min(n_full, 200000)
@@ -571,7 +645,6 @@ def main():
         train = {"unit": "us/step", "batch": 2048, "model_step_us": model_us, "model_tflops": fl_model / model_us / 1e6,
                  "critic_step_us": critic_us, "model": f"E={E} {D + A}->{H}->{H}->{2 * (D + 1)} MSPE + Adam",
                  "critic": "E=3 obs->128->128->1 MSE + Adam", "per_rank": True}
-        res_host = [x[:n50].cpu() for x in res]       # for the CPU update baseline, before the buffers are released
         del res, obs_t, act_t, ret_t, x_dyn, t_dyn
 
     roof = ens_roofline(w, events)
@@ -601,9 +674,14 @@ def main():
                      ("humanoid_b10k_h14", "HumanoidSafe-v2", 10000, 15, "schedule"),
                      ("hopper_b10k_h14", "HopperSafe-v2", 10000, 15, "schedule"),
                      ("antsafe_b1000", "AntSafe-v2", 1000, 35, "schedule"),
-                     ("antsafe_b1000_uncertainty_budget", "AntSafe-v2", 1000, 35, "uncertainty"),
-                     ("antsafe_b100k_uncertainty_budget", "AntSafe-v2", 100000, 35, "uncertainty")):
+                     ("antsafe_b1000_uncertainty_dies_of_dkl", "AntSafe-v2", 1000, 35, "uncertainty"),
+                     ("antsafe_b100k_uncertainty_dies_of_dkl", "AntSafe-v2", 100000, 35, "uncertainty")):
             subs.append(run_config(*spec, device))
+        # the shipped stop rule: 'uncertainty' rollouts that end because the sample budget binds (a DKL limit most
+        # branches stay under for the phase, max_samples = BUDGET_FRAC * B * T)
+        for spec in (("antsafe_b1000_uncertainty_budget_binds", "AntSafe-v2", 1000, 35, "uncertainty"),
+                     ("antsafe_b100k_uncertainty_budget_binds", "AntSafe-v2", 100000, 35, "uncertainty")):
+            subs.append(run_config(*spec, device, dkl_scale=BIND_DKL_SCALE, budget_frac=BIND_BUDGET_FRAC, budget_binds=True))
 
     if rank == 0:
         arith = {
@@ -631,8 +709,13 @@ def main():
                                    f"3+3 critics 128x128, tanh policy 128x128, "
                                    + (f"B={args.branches} branches sharded over {world} GPU(s)" if args.scaling == "strong"
                                       else f"B={B} branches/GPU")
-                                   + f", maxroll {maxroll} ({maxroll - 1} steps), fixed-horizon mode, "
-                                     f"reset->sample*->finish_all_paths->get()",
+                                   + f", maxroll {maxroll} ({maxroll - 1} steps), "
+                                   + ("fixed-horizon mode" if args.rollout_mode == "schedule" else
+                                      f"'uncertainty' mode (DKL limit {args.dkl_scale} x the 5-step calibration)")
+                                   + (f", max_samples = {max_samples} (budget rule)" if max_samples else "")
+                                   + ", reset->sample*->finish_all_paths->get()",
+                       "rollout_mode": args.rollout_mode, "max_samples": max_samples, "dkl_lim": dkl_lim,
+                       "n_budget_terminated_per_phase": n_budget / args.steps, "sampler_steps_per_phase_rank0": n_steps / args.steps,
                        "branches_per_gpu": B, "branches_total": args.branches if args.scaling == "strong" else B * world,
                        "horizon": maxroll - 1, "task": task, "samples_per_step": tot / args.steps, "arithmetic": arith},
             "roofline": roof,
@@ -646,7 +729,7 @@ def main():
         if extras and not args.no_cpu_baseline and world == 1:     # the CPU baseline is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(w, task, seconds=args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-            out["cpu_baseline"]["cpo_update_ms_50k"] = cpu_update_baseline(w, res_host, n50)
+            out["cpu_baseline"]["cpo_update_ms_50k"] = cpu_update_baseline(w, cbuf_host, n50, c_lim, maxroll)
             out["cpu_baseline"]["model_train_step_us"] = cpu_train_baseline(E, D + A, H, 2 * (D + 1), "MSPE", 2048)
             out["cpu_baseline"]["critic_train_step_us"] = cpu_train_baseline(3, D, 128, 1, "MSE", 2048)
         print(json.dumps(out), flush=True)

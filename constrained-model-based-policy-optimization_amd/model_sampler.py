@@ -164,6 +164,7 @@ class ModelSampler:
         self._n_episodes = 0
         self.global_alive = 1
         self._global_total_samples = 0.0
+        self.n_budget_terminated = 0     # branches the `max_samples` rule ended early (model_sampler.py:282-287), this shard
         self._host = dict(total_samples=0.0, total_dkl=0.0)
         elites = np.asarray(self.env._model.elite_inds, dtype=np.int32)
         self._elites = torch.as_tensor(elites, device=self.device)
@@ -260,6 +261,7 @@ class ModelSampler:
                 pool._call("cmbpo_rollout_finish", 1)
             # the host sync of the step: counters of what finished / was stored + the accumulators
             isc, dsc = self._read_scalars()
+            self.n_budget_terminated += int(isc[_lib.I_N_FIN_PRE]) - int(isc[_lib.I_N_UNC])
             if compacted:
                 pool.swap("alive_idx", "alive_idx_out")
             elif int(isc[_lib.I_N_FIN_PRE]) + int(isc[_lib.I_N_FIN_POST]) > 0:
@@ -331,6 +333,7 @@ class ModelSampler:
         if rc != 1:
             _lib.check(rc, "cmbpo_rollout_step")
         isc, dsc = self._read_scalars()         # the host sync of the step
+        self.n_budget_terminated += int(isc[_lib.I_N_FIN_PRE]) - int(isc[_lib.I_N_UNC])
         if rc == 1:                             # small batch: finish(POST) and the compaction ran inside the call
             pool.swap("alive_idx", "alive_idx_out")
         elif int(isc[_lib.I_N_FIN_PRE]) + int(isc[_lib.I_N_FIN_POST]) > 0:
@@ -423,6 +426,8 @@ class ModelSampler:
                 self._n_episodes += done
                 steps += done
                 left -= done
+                blk = self._run_host[:done, :128].view(torch.int32).numpy()
+                self.n_budget_terminated += int(blk[:, _lib.I_N_FIN_PRE].sum() - blk[:, _lib.I_N_UNC].sum())
                 last = self._run_host[done - 1]
                 isc, dsc = last[:128].view(torch.int32).numpy().copy(), last[128:].view(torch.float64).numpy().copy()
                 pool._n_alive, pool._size = alive_o.value, int(isc[_lib.I_SIZE])

@@ -171,3 +171,46 @@ def test_rollout_properties_at_bench_size(hip_lib):
     assert bool((ls == -0.5).all())
     # the buffer is reset and reusable: a second rollout from the same states with the same draws is identical
     assert pool.n_alive == B and pool.size == 0
+
+
+def test_rollout_properties_at_config5_shard(hip_lib):
+    """BASELINE config 5's per-rank shape (1 M branches x horizon 25 over 8 GPUs = 125 000 branches, maxroll 26) on one
+    GPU, 'uncertainty' mode with a sample budget that binds: size-independent properties of the whole phase."""
+    _need_gpu()
+    import bench
+    from cmbpo_amd import synthetic
+    task, B, T = "AntSafe-v2", 125000, 26
+    w = bench.build_world(0, task)
+    sampler, pool, env, policy = bench.build_hip(w, task, B, torch.device("cuda:0"), maxroll=T, mode="uncertainty")
+    start = synthetic.start_states(np.random.default_rng(6), B, task)
+    start_t = torch.from_numpy(start).cuda()
+    sampler.reset(start_t)
+    lim = float(sampler.compute_dynamics_dkl(start_t[:5000], depth=5)) * bench.BIND_DKL_SCALE
+    sampler.set_rollout_dkl(lim)
+    budget = int(0.5 * B * (T - 1))
+    sampler.reset(start_t)
+    steps = 0
+    while sampler.any_alive() and pool.has_room:
+        k, info = sampler.sample_many(max_samples=budget)
+        steps += k
+    lens = pool.t["len"].cpu().numpy()
+    diag = sampler.finish_all_paths()
+    res, bdiag = pool.get(as_tensors=True)
+    n = int(lens.sum())
+    # the budget rule is exact: the step that would pass max_samples stores only what is left of it, the next one ends
+    # every surviving branch (samplers/model_sampler.py:282-287)
+    assert n == budget == int(diag["msampler/samples_added"]) == bdiag["poolm_batch_size"]
+    assert sampler.n_budget_terminated > 0 and steps >= 12 and lens.max() <= T - 1
+    obs, act, adv, cadv, ret, cret, logp, val, cval, cost, ls, mu = res
+    assert obs.shape == (n, 29) and act.shape == (n, 8) and adv.shape == (n,)
+    offs = np.concatenate([[0], np.cumsum(lens)])[:-1]
+    has = lens > 0
+    np.testing.assert_array_equal(obs[torch.from_numpy(offs[has]).cuda()].cpu().numpy(), start[has])
+    # early termination takes the FIRST surviving rows in index order: among the branches the budget ended at the last
+    # two steps, lower ids are never longer than higher ids that survived the same step
+    assert abs(float(adv.double().mean())) < 1e-4 and abs(float(adv.double().std(unbiased=False)) - 1.0) < 1e-4
+    assert abs(float(cadv.double().mean())) < 1e-5
+    for t_ in (ret, cret, logp, val, cval, mu, obs, act):
+        assert bool(torch.isfinite(t_).all())
+    assert set(np.unique(cost.cpu().numpy())) <= {0.0, 1.0}
+    assert pool.n_alive == B and pool.size == 0

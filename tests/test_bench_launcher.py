@@ -72,3 +72,23 @@ def test_gpus2_runs_the_rollout_on_two_ranks():
         out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
         assert out["n_gpus"] == 2 and out["config"]["branches_total"] == total
         assert out["value"] > 0 and out["config"]["samples_per_step"] == total * 5      # every branch lives 5 steps
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_gpus2_strong_config5_shards_with_a_binding_budget():
+    """BASELINE config 5's shard at size: 250 000 branches x maxroll 26 as two contiguous shards of 125 000 (the per-rank
+    shape of 1 M over 8), 'uncertainty' mode with a max_samples that binds -- the cross-rank budget plan (one all-gather
+    per step, dist.budget_plan) decides the early terminations.  Two ranks on this box's one GPU over gloo."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-extras", "--scaling", "strong", "--branches", "250000",
+              "--maxroll", "26", "--rollout-mode", "uncertainty", "--budget-frac", "0.5"], {"CMBPO_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 2 and cfg["branches_total"] == 250000 and cfg["branches_per_gpu"] == 125000
+    assert cfg["max_samples"] == int(0.5 * 250000 * 25)
+    assert cfg["samples_per_step"] == cfg["max_samples"]              # the job's budget, met exactly across the two shards
+    assert cfg["n_budget_terminated_per_phase"] > 0 and cfg["sampler_steps_per_phase_rank0"] >= 12

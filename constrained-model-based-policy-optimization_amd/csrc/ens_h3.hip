@@ -36,6 +36,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace {
 
 constexpr int kThreadsH = 512;
@@ -158,6 +160,19 @@ __global__ void h3_pack_kernel(const float *src, size_t src_stride, int kg, int 
   d[0] = p1; d[64] = p2;
 }
 
+// compile-time loop: f(integral_constant<int, I>) for I in [I0, N) -- indices of register arrays must be constants
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+#ifndef H3_TAIL_RING
+#define H3_TAIL_RING 0      // diagnostic: 1 = W2 fragments through the two-slab ring for every shape (round 2's tail)
+#endif
+
 struct H3Args {
   MlpKernelArgs m;
   const f16x8 *w0, *w1, *w2;
@@ -244,6 +259,9 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
   const unsigned long long t_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
+#ifdef H3_EXP_PRIO
+  if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1);     // the second-dispatched half loses every arbitration otherwise
+#endif
   for (int item = a.item0 + blockIdx.x; item < p.n_items; item += gridDim.x) {
     // the thread index, re-read inside the loop through an opaque move: everything derived from it is recomputed per
     // item instead of being hoisted out of the loop and parked in scratch (the loop body needs every register)
@@ -446,11 +464,15 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
           const int sl = pos / RT, bt = pos % RT;
           const int t = (i / 3) % 2, term = i % 3;
           if (i % 6 == 0) {
+#ifndef H3_DIAG_NOA
             if (bt == 0) {                                         // a new slab: request the one DA - 1 ahead
               const int sn = c * SLC + sl + DA - 1;
               load_a(A[(sl + DA - 1) % DA], sn < 32 ? sn : 31);
             }
+#endif
+#ifndef H3_DIAG_NOBT
             if (pos + 2 < 16) read_bt(Bt[(pos + 2) % 3], img, (pos + 2) % RT, (pos + 2) / RT);
+#endif
             if (i == 0) __builtin_amdgcn_sched_barrier(0);
           }
           f16x8(&Ac)[2][2] = A[sl % DA];
@@ -459,11 +481,17 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
           if (term == 0) ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[t][1], b1, ac, 0, 0, 0);
           else if (term == 1) ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[t][0], b2, ac, 0, 0, 0);
           else ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[t][0], b1, ac, 0, 0, 0);
+#ifndef H3_DIAG_NOL0
           if (slot < S0 && i == 5) {          // layer-0 MFMAs of input slab `slot`, then the next slab's operands
             mm3(d, l0.a1, l0.a2, l0.b1, l0.b2);
             if (slot + 1 < S0) l0_read(l0, c + 1, slot + 1);
           }
+#endif
+#ifdef H3_DIAG_NOEPI_LOOP
+          if (false) {
+#else
           if (slot >= 4) {
+#endif
             const int q = slot - 4;
             if (i == 0) epi_stage<0, true>(es, d, q, inv0_l, bv, t1_l);
             if (i == 1) epi_stage<1, true>(es, d, q, inv0_l, bv, t1_l);
@@ -495,6 +523,20 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
     fetch_x(tid);
     fetch_bias(item + gridDim.x, tid);
     H3_STAMP(6);
+#ifdef H3_DIAG_NOTAIL
+    {
+      float keep = 0.0f;      // every accumulator register stays live: the loop's MFMAs must all execute
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int bt = 0; bt < RT; ++bt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) keep += acc[t][bt][i];
+      if (keep == 123.456f) p.out0[0] = keep;
+    }
+    __syncthreads();
+    continue;
+#endif
 
     // ---- tail: h2 -> output layer -> head -> stores, one (32-row tile, pair of output tiles) unit at a time.
     // h2 never leaves the registers: an accumulator tile's rows are the next product's k index, so the wave's own 64 hidden
@@ -537,6 +579,65 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
         }
       }
     };
+    if constexpr (NPASS == 1 && !H3_TAIL_RING) {
+      // Two output tiles (every shipped task but Humanoid): the wave's 16 W2 fragments (its 4 slabs x 2 tiles x 2 pieces)
+      // stay in 64 registers for the four row tiles of the item -- requested once, behind the first row tile's epilogue,
+      // instead of once per row tile (a third of the item's L2 -> CU traffic, and an L2 round trip in front of every slab's
+      // MFMAs: the chip holds its clock by power, and weight fragments from L2 are what costs most of it beside the MFMAs).
+      f16x8 w2r[4][2][2];      // [slab][output tile][piece]
+      static_for<0, 4>([&](auto SI) {
+        constexpr int S = decltype(SI)::value;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const f16x8 *q = w2w + ((size_t)tt * 32 + S) * 128;
+          w2r[S][tt][0] = q[0]; w2r[S][tt][1] = q[64];
+        }
+      });
+      static_for<0, RT>([&](auto RTI) {
+        constexpr int rt = decltype(RTI)::value;
+        f16x8 bf[4][2];
+        {
+          u32x4 bfu[4][2];
+          const float inv1_l = r_inv1[32 * rt + r], t2_l = r_t2[32 * rt + r];
+          static_for<0, 8>([&](auto QD) {
+            constexpr int quad = decltype(QD)::value, S = quad >> 1, jq = quad & 1, q = 2 * (S & 1) + jq;
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias1 + 64 * wave + 32 * (S >> 1) + 8 * q + 4 * hh);
+            Epi4 es;
+            epi_all<false>(es, acc[S >> 1][rt], q, inv1_l, bv, t2_l);
+            bfu[S][0][2 * jq] = es.q1[0]; bfu[S][0][2 * jq + 1] = es.q1[1];
+            bfu[S][1][2 * jq] = es.q2[0]; bfu[S][1][2 * jq + 1] = es.q2[1];
+          });
+#pragma unroll
+          for (int S = 0; S < 4; ++S)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) bf[S][pc] = __builtin_bit_cast(f16x8, bfu[S][pc]);
+        }
+        f32x16 o[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[tt][i] = 0.0f;
+        static_for<0, 4>([&](auto SI) {
+          constexpr int S = decltype(SI)::value;
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) mm3(o[tt], w2r[S][tt][0], w2r[S][tt][1], bf[S][0], bf[S][1]);
+        });
+        f32x4 *pw = pbuf + ((size_t)(rt & 1) * 64 + (size_t)wave * 8) * 64 + lane;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {o[tt][4 * q], o[tt][4 * q + 1], o[tt][4 * q + 2], o[tt][4 * q + 3]};
+            pw[(size_t)(tt * 4 + q) * 64] = v;
+          }
+        H3_STAMP(7);
+        __syncthreads();       // unit rt's partials are complete; unit rt - 1's staging tile too
+        H3_STAMP(8);
+        if (rt > 0) store_unit(rt - 1);
+        reduce_unit(rt);
+        H3_STAMP(9);
+      });
+    } else {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       f16x8 wf[2][2][2];       // [ping-pong][output tile of the pair][piece]
@@ -599,6 +700,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
         reduce_unit(u);
         H3_STAMP(9);
       }
+    }
     }
     __syncthreads();
     store_unit(NUNIT - 1);

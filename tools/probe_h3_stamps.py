@@ -5,8 +5,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = os.path.join(ROOT, "constrained-model-based-policy-optimization_amd")
 so = "/tmp/libcmbpo_stamps.so"
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                       "-ffp-contract=off", "-DCMBPO_STAMPS"] + sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip"))) + ["-o", so])
+EXTRA = sys.argv[2].split() if len(sys.argv) > 2 else []      # extra -D flags of the ens_h3.hip variant under test
+objs = []
+for src in sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip"))):      # every file: MlpKernelArgs carries the stamp pointer
+    o = "/tmp/st_" + os.path.basename(src)[:-4] + ".o"
+    if not (os.path.exists(o) and os.path.getmtime(o) > os.path.getmtime(src)) or src.endswith("ens_h3.hip"):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                               "-DCMBPO_STAMPS"] + (["-fno-slp-vectorize"] + EXTRA if src.endswith("ens_h3.hip") else []) +
+                              ["-c", src, "-o", o])
+    objs.append(o)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", so])
 import numpy as np, torch
 import cmbpo_amd
 from cmbpo_amd import _lib

@@ -21,6 +21,19 @@ constexpr float T_TANH_INV = 1.0f / 16384.0f;
 constexpr int RSH = 2 * RS;             // row stride of a two-piece image, in halves
 constexpr int P2H = HID;                // offset of the second piece inside a row, in halves
 constexpr int RW = 4;                   // slabs in the matrix ring
+// saved activations of a tile on this path: the LDS block [h1 two-piece image | h2 fp32 rows] as it stands, row padding
+// included (2 x 32 x RS floats): cmbpo_pi_loss_grad copies it out, a product on the saved activations copies it back
+// with LDS-DMA -- no registers, no split, no LDS stores
+constexpr int ACT_TILE4 = 2 * BB * RS / 4;                 // float4s per tile
+constexpr int ACT_PIECES = (ACT_TILE4 * 16 + 1023) / 1024; // 1-KiB wave-instructions per tile (the last one partly past the block)
+
+// A barrier that orders the workgroup's LDS traffic only.  __syncthreads() is a workgroup-scope fence + s_barrier: hipcc waits
+// vmcnt(0) in front of it, i.e. for every global load still in flight -- the per-sample batch columns requested at the top
+// of a tile for its element phase, the next tile's observations, the matrix ring: each became an exposed L2 / HBM round
+// trip at the next barrier (the first barrier of a tile alone waited ~3 k cycles).  Here only the LDS counter is drained;
+// the compiler still tracks the loads and waits for each one where its value is used.  NOT for a barrier that publishes
+// LDS-DMA data (counted in vmcnt): the one that ends a tile stays a __syncthreads().
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ float pow2_inv(float t) {   // exact inverse of a power of two in [2^-126, 2^126]
   return __uint_as_float(0x7F000000u - __float_as_uint(t));
@@ -191,14 +204,35 @@ __device__ __forceinline__ void gemm_r(f32x16 &acc, Ring &R, const u32x4 *(&imgs
 }
 
 // ---- weight gradients: K = the tile's 32 samples ----------------------------------------------------------------------
-// the two-piece fragment of eight samples b = b0 + e of column c: from a two-piece image ...
-__device__ __forceinline__ void frag_T(const _Float16 *img, int b0, int c, f16x8 &p1, f16x8 &p2) {
-  const _Float16 *q = img + b0 * RSH + c;
+// the two-piece fragment of eight samples b = b0 + e (b0 = 8 (lane >> 5) + ks) of column c0 + (lane & 31), from a two-piece
+// [sample][unit] image: the hardware's transposed read (ds_read_b64_tr_b16: a 16-lane group reads a block of 4 rows x 16
+// columns of halves, lane 4 q + p supplies the address of row q, columns 4 p .. 4 p + 3, and lane i receives column i of the
+// 4 rows) delivers four samples of one unit per read -- 4 reads per fragment pair instead of 16 two-byte gathers and the
+// ~12 permutes that packed them.  EXEC must be all ones (the gather crosses lanes): every call site is workgroup-uniform.
+typedef __fp16 h16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ void frag_T(const _Float16 *img, int ks, int c0, f16x8 &p1, f16x8 &p2, int lane) {
+#ifdef PI_FRAG_GATHER      // diagnostic: round 2's two-byte gathers
+  const _Float16 *q = img + (8 * (lane >> 5) + ks) * RSH + c0 + (lane & 31);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     p1[e] = q[e * RSH];
     p2[e] = q[e * RSH + P2H];
   }
+  return;
+#endif
+  typedef __attribute__((address_space(3))) h16x4 *lds_h4;
+  const int t = lane & 15, g = lane >> 4;
+  const _Float16 *a = img + (8 * (g >> 1) + ks + (t >> 2)) * RSH + c0 + 16 * (g & 1) + 4 * (t & 3);
+  const h16x4 lo1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)a);
+  const h16x4 hi1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(a + 4 * RSH));
+  const h16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(a + P2H));
+  const h16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(a + 4 * RSH + P2H));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 l1 = __builtin_bit_cast(u32x2, lo1), h1 = __builtin_bit_cast(u32x2, hi1);
+  const u32x2 l2 = __builtin_bit_cast(u32x2, lo2), h2 = __builtin_bit_cast(u32x2, hi2);
+  const u32x4 q1 = {l1[0], l1[1], h1[0], h1[1]}, q2 = {l2[0], l2[1], h2[0], h2[1]};
+  p1 = __builtin_bit_cast(f16x8, q1);
+  p2 = __builtin_bit_cast(f16x8, q2);
 }
 // ... and from an fp32 row image, split as it is read
 __device__ __forceinline__ void frag_Ts(const float *img, int stride, int b0, int c, float t, f16x8 &p1, f16x8 &p2) {
@@ -231,15 +265,14 @@ __device__ __forceinline__ float frag_sum(const f16x8 (&b1)[2], const f16x8 (&b2
 // colsum += sum_b Y[b][32 jsum + j] (the two lane halves hold the two halves of the samples)
 __device__ __forceinline__ void wgrad_h(f32x16 (&g)[4], const _Float16 *X, int i0, const _Float16 *Y, float unscale, float y_unscale,
                                         int jsum, float &colsum, int lane) {
-  const int i = lane & 31, b0 = 8 * (lane >> 5);
   f16x8 a1[2], a2[2];
-  frag_T(X, b0, i0 + i, a1[0], a2[0]);
-  frag_T(X, b0 + 16, i0 + i, a1[1], a2[1]);
+  frag_T(X, 0, i0, a1[0], a2[0], lane);
+  frag_T(X, 16, i0, a1[1], a2[1], lane);
 #pragma unroll
   for (int J = 0; J < 4; ++J) {
     f16x8 b1[2], b2[2];
-    frag_T(Y, b0, 32 * J + i, b1[0], b2[0]);
-    frag_T(Y, b0 + 16, 32 * J + i, b1[1], b2[1]);
+    frag_T(Y, 0, 32 * J, b1[0], b2[0], lane);
+    frag_T(Y, 16, 32 * J, b1[1], b2[1], lane);
     f32x16 tmp;
     zero(tmp);
     mm3(tmp, a1[0], a2[0], b1[0], b2[0]);
@@ -363,19 +396,23 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
     __syncthreads();
   }
 
-  // saved activations: a tile's two images travel L2 -> registers while the previous tile ends (they were pulled from HBM
-  // into L2 by the warm-up touch a phase earlier); requested any sooner, the 32 registers spill across the weight gradients
-  // (h1 only: with h2's 16 registers as well, the end of the tile spills; and only the one-row-tile input layer has
-  // those 16 to spare)
-  constexpr bool ACT_PRE = !FWD && N_IT == 1;
-  f32x4 act1[4];
-  auto fetch_act = [&](int t, int tid) {
-    const f32x4 *src = p.cache_r + (size_t)t * (2 * IMG4);
+  // saved activations: a tile's block [h1 image | h2 rows] travels global -> LDS by LDS-DMA (one wave-instruction = 64 lanes x
+  // 16 B = 1 KiB, destination = wave-uniform base + 16 lane), requested as soon as the previous tile has no reader of the
+  // two images left (behind its dW2: only dW0 follows, on x and delta1) and drained by the barrier that ends the tile
+  constexpr bool ACT_DMA = !FWD;
+  auto fetch_act = [&](int t, int lane_) {
+    const char *src = reinterpret_cast<const char *>(p.cache_r + (size_t)t * ACT_TILE4);
+    char *dst = reinterpret_cast<char *>(h1R);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) act1[i] = src[tid + kThreads * i];
+    for (int k = 0; k < (ACT_PIECES + 3) / 4; ++k) {
+      const int pc = wave + 4 * k;
+      if (pc < ACT_PIECES)      // (wave-uniform)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)pc * 1024 + lane_ * 16),
+                                         (__attribute__((address_space(3))) void *)(dst + pc * 1024), 16, 0, 0);
+    }
   };
-  if constexpr (ACT_PRE) {
-    if ((int)blockIdx.x < n_tiles) fetch_act(blockIdx.x, tid0);
+  if constexpr (ACT_DMA) {
+    if ((int)blockIdx.x < n_tiles) fetch_act(blockIdx.x, tid0 & 63);
   }
 #ifdef CMBPO_STAMPS
   unsigned long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -436,34 +473,14 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
     f32x16 acc;
     float t_x = 1.0f, it_x = 1.0f;
     if constexpr (!FWD) {
-      // ---- h1, h2 as cmbpo_pi_loss_grad left them (same parameters, same batch): h1 is split the way the forward pass
-      // splits it, so the products see identical bits
-      // (h1 was requested at the end of the previous tile, behind its last weight gradient)
-      f32x4 act2[4];
-      {
-        const f32x4 *src = p.cache_r + (size_t)tile * (2 * IMG4);
-        if constexpr (!ACT_PRE) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) act1[i] = src[tid + kThreads * i];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) act2[i] = src[IMG4 + tid + kThreads * i];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int idx = tid + kThreads * i, b = idx >> 5, c = idx & 31;
-        unsigned q1[2], q2[2];
-        split2<false>(act1[i][0], act1[i][1], T_TANH, q1[0], q2[0]);
-        split2<false>(act1[i][2], act1[i][3], T_TANH, q1[1], q2[1]);
-        *reinterpret_cast<uint2 *>(h1H + b * RSH + 4 * c) = make_uint2(q1[0], q1[1]);
-        *reinterpret_cast<uint2 *>(h1H + b * RSH + 4 * c + P2H) = make_uint2(q2[0], q2[1]);
-        reinterpret_cast<f32x4 *>(h2R)[b * (RS / 4) + c] = act2[i];
-      }
-      __syncthreads();
+      // ---- h1, h2 as cmbpo_pi_loss_grad left them (same parameters, same batch): the LDS block itself, so the products
+      // see identical bits; it was requested behind the previous tile's dW2 (before the loop for the first tile) and the
+      // barrier that ended that tile waited for it
+      lds_barrier();
       t_x = pow2_lift(__uint_as_float(mx[0]));
       it_x = pow2_inv(t_x);
     } else {
-      __syncthreads();
+      lds_barrier();
       t_x = pow2_lift(__uint_as_float(mx[0]));
       it_x = pow2_inv(t_x);
       // ---- forward ----------------------------------------------------------------------------------
@@ -477,22 +494,8 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) hv[r] = cmbpo_fast_tanh(acc[r] * un);
         store_tile_H(hv, wave * 32, h1H, T_TANH, lane);
-        if constexpr (MODE == MODE_GRAD) {
-          // the fp32 h1 is saved from the registers (its LDS image holds the two pieces): a product that reads it back
-          // splits the same bits the same way
-          if (p.cache_w != nullptr) {
-            f32x4 *dst = p.cache_w + (size_t)tile * (2 * IMG4) + j * 32 + wave * 8 + h;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              f32x4 xq;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) xq[e] = hv[4 * q + e];
-              dst[2 * q] = xq;
-            }
-          }
-        }
       }
-      __syncthreads();
+      lds_barrier();
       acc = load_bias(p.w.b1, wave * 32, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] *= p.w.lift[L_F1] * T_TANH;
@@ -504,15 +507,12 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
         for (int r = 0; r < 16; ++r) hv[r] = cmbpo_fast_tanh(acc[r] * un);
         store_tile_R(hv, wave * 32, h2R, RS, lane);
       }
-      __syncthreads();
+      lds_barrier();
       if constexpr (MODE == MODE_GRAD) {
-        if (p.cache_w != nullptr) {
-          f32x4 *dst = p.cache_w + (size_t)tile * (2 * IMG4);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int idx = tid + kThreads * i, b = idx >> 5, c = idx & 31;
-            dst[IMG4 + idx] = h2R4[b * (RS / 4) + c];
-          }
+        if (p.cache_w != nullptr) {      // both images are complete behind the barrier: the block as it stands
+          f32x4 *dst = p.cache_w + (size_t)tile * ACT_TILE4;
+          const f32x4 *blk = reinterpret_cast<const f32x4 *>(h1R);
+          for (int i = tid; i < ACT_TILE4; i += kThreads) dst[i] = blk[i];
         }
       }
     }
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
         for (int r = 0; r < 16; ++r) acc[r] *= mv;
       }
       PI_STAMP(2);
-      __syncthreads();
+      lds_barrier();
       PI_STAMP(3);
       gemm_r<ST, P_WF1J, 8, false>(acc, R, imgs, BImg{u1H + j * RSH + 8 * h}, lane);
       {
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
       zero(acc);
       gemm_r<ST, P_VF2, 2, false>(acc, R, imgs, BSplit{h2R + j * RS + 32 * wave + 8 * h, T_TANH}, lane);
       PI_STAMP(5);
-      __syncthreads();   // dh2 complete; every wave is done reading dh1 (u1R becomes the reduction image)
+      lds_barrier();   // dh2 complete; every wave is done reading dh1 (u1R becomes the reduction image)
       PI_STAMP(6);
       {
         const float t_d = pow2_lift(__uint_as_float(mx[2])), it_d = pow2_inv(t_d);
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
       const int a = (r & 3) + 8 * (r >> 2) + 4 * h;
       red[(wave * 32 + a) * RED_LD + j] = acc[r];
     }
-    __syncthreads();
+    lds_barrier();
 
     PI_STAMP(7);
     // ---- element phase over (a, b): this thread owns b = tid & 31, a = tid/32 + 8*it ------------------
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
       }
     }
     if constexpr (MODE != MODE_FVP) {
-      __syncthreads();
+      lds_barrier();
       float logp = 0.0f;
       for (int a = 0; a < d.A; ++a) logp += wR[eb * 36 + a];
       const float ratio = valid ? expf(logp - e_logp) : 0.0f;                // cpo_policy.py:522
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
         s_rc += (double)(ratio * cadv);
         s_cost += (double)p.cost[er];
       }
-      __syncthreads();   // every thread has read the scratch terms before they are overwritten
+      lds_barrier();   // every thread has read the scratch terms before they are overwritten
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int a = (tid >> 5) + 8 * it;
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
     }
     if constexpr (MODE != MODE_EVAL) thread_max_put(cmax, &mx[1], lane);
     if (tid < 4) s_mx[parity ^ 1][tid] = 0u;     // the other parity's maxima were last read a tile ago
-    __syncthreads();
+    lds_barrier();
     PI_STAMP(8);
     if constexpr (MODE == MODE_EVAL) continue;
 
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
       for (int r = 0; r < 16; ++r) o[r] = (1.0f - hh[r] * hh[r]) * (acc[r] * un);
       store_tile_H(o, wave * 32, u2H, t2, lane);     // dh2 is dead (the barrier after the reduction image)
     }
-    __syncthreads();
+    lds_barrier();
     PI_STAMP(9);
     zero(acc);
     gemm_r<ST, P_WB1, 8, true>(acc, R, imgs, BImg{u2H + j * RSH + 8 * h}, lane);
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
       // touch one dword of each 128-B line of the NEXT tile's saved activations: they travel HBM -> L2 behind the
       // MFMAs below, and the loads at the top of the next iteration hit L2
       const int nxt = tile + gridDim.x;
-      if (nxt < n_tiles) warm = reinterpret_cast<const float *>(p.cache_r + (size_t)nxt * (2 * IMG4))[tid * 32];
+      if (nxt < n_tiles) warm = reinterpret_cast<const float *>(p.cache_r + (size_t)nxt * ACT_TILE4)[tid * 32];
     }
     // dW1 and dW2 need delta2 / the cotangent only (complete since the previous barrier): they run while the slower
     // waves still write delta1
@@ -723,8 +723,11 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
       float unused = 0.0f;
       wgrad_s<false>(gW2, h2R, RS, wave * 32, T_TANH, wR, 36, 0, t_c, T_TANH_INV * it_c, 0.0f, unused, lane);
     }
-    __syncthreads();   // delta1 complete
+    lds_barrier();   // delta1 complete; no wave reads h1 / h2 any more
     PI_STAMP(12);
+    if constexpr (ACT_DMA) {
+      if (tile + (int)gridDim.x < n_tiles) fetch_act(tile + gridDim.x, lane);
+    }
     {
       const float t_d1 = pow2_lift(__uint_as_float(mx[3])), it_d1 = pow2_inv(t_d1);
       float unused = 0.0f;
@@ -733,11 +736,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
     }
     asm volatile("" ::"v"(warm));   // the warm-up load must be issued, its value is not used
     ring_fill<ST>(R, imgs, lane);   // the next tile's first slabs: they land behind its staging
-    if constexpr (ACT_PRE) {
-      __builtin_amdgcn_sched_barrier(0);     // (not above the weight gradient: its fragments need the registers)
-      if (tile + (int)gridDim.x < n_tiles) fetch_act(tile + gridDim.x, tid);
-    }
-    __syncthreads();
+    __syncthreads();                // (waits for the LDS-DMA of the next tile's saved activations as well)
     PI_STAMP(13);
   }
 #ifdef CMBPO_STAMPS

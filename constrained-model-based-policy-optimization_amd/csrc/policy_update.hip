@@ -736,6 +736,7 @@ struct cmbpo_pi {
   float *act;
   size_t act_tiles;       // capacity
   bool act_keep, act_valid;
+  int act_path;           // the matrix path that wrote them
   const float *act_obs;   // the batch the saved activations belong to
   int act_n;
   long act_hits;          // Fisher-vector products that read the saved activations (diagnostics)
@@ -880,7 +881,9 @@ int fill_args(cmbpo_pi *h, const cmbpo_pi_batch_t *b, PiArgs &a, const char *who
 
 // the saved activations a Fisher-vector product on batch b may read, or NULL
 const f32x4 *act_for(const cmbpo_pi *h, const cmbpo_pi_batch_t *b) {
-  if (!h->act_keep || !h->act_valid || h->act == nullptr || b->obs != h->act_obs || b->n != h->act_n) return nullptr;
+  if (!h->act_keep || !h->act_valid || h->act == nullptr || b->obs != h->act_obs || b->n != h->act_n ||
+      h->act_path != pi_path())      // (the two matrix paths keep different images)
+    return nullptr;
   return reinterpret_cast<const f32x4 *>(h->act);
 }
 
@@ -891,7 +894,9 @@ bool act_reserve(cmbpo_pi *h, int n) {
   h->act_valid = false;
   if (h->act) (void)hipFree(h->act);      // synchronises: nothing in flight still reads the old block
   h->act = nullptr; h->act_tiles = 0;
-  if (hipMalloc(reinterpret_cast<void **>(&h->act), tiles * 2 * BB * HID * sizeof(float)) != hipSuccess) {
+  // (per tile: the fp32 kernels keep two dense [32][128] images, the f16 kernels the padded LDS block -- room for the larger,
+  //  plus a KiB: the last LDS-DMA piece of a block reads past its end)
+  if (hipMalloc(reinterpret_cast<void **>(&h->act), tiles * 2 * BB * RS * sizeof(float) + 1024) != hipSuccess) {
     (void)hipGetLastError();
     h->act = nullptr;
     return false;
@@ -1001,7 +1006,7 @@ extern "C" int cmbpo_pi_loss_grad(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, int 
   const bool save = h->act_keep && act_for(h, b) == nullptr && act_reserve(h, b->n);
   if (save) a.cache_w = reinterpret_cast<f32x4 *>(h->act);
   if (int rc = launch_pi<MODE_GRAD>(h, a, s)) return rc;
-  if (save) { h->act_valid = true; h->act_obs = b->obs; h->act_n = b->n; }
+  if (save) { h->act_valid = true; h->act_obs = b->obs; h->act_n = b->n; h->act_path = pi_path(); }
   return CMBPO_OK;
 }
 

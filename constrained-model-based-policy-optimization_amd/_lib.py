@@ -96,6 +96,7 @@ SIGNATURES.update({
                                C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _p]),
     "cmbpo_buffer_offsets": (_i, [_rp, _p, _p]),
     "cmbpo_buffer_moments": (_i, [_rp, _i, _p, _p]),
+    "cmbpo_buffer_prepare": (_i, [_rp, _p, _p, _p]),
     "cmbpo_buffer_flatten": (_i, [_rp, _p, _p, C.POINTER(C.c_void_p), _p]),
 })
 

@@ -740,6 +740,120 @@ __global__ void moments_finalize(int pass, double *st) {
   }
 }
 
+// ---- get() on one GPU: the scan and both moment passes as TWO launches ----------------------------------------------------
+// (the separate kernels above remain for the sharded path, where an all-reduce stands between the passes).  A workgroup =
+// 256 consecutive branches: its path-length sum and its float64 partial moments go to r.store_part[block][0..5]; the LAST
+// workgroup to arrive (device-scope counter) scans the block sums, adds the partial moments in block order -- the statistics
+// stay bitwise reproducible -- and finishes the means.  The second launch writes every branch's offset and the partial sums
+// of (adv - mean)^2 (float32 differences, utilities/mpi_tools.py:86), and its last workgroup finishes the standard deviation.
+// store_part row: [0] n  [1] sum adv  [2] sum cadv  [3] sum ret  [4] sum cret  [5] samples of the block  [6] its offset  [7] sum (adv - mean)^2
+__device__ __forceinline__ bool last_block_arrives(int *counter) {
+  __shared__ int s_last;
+  __threadfence();                      // this workgroup's partial row is visible device-wide before the count
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(counter, 1) == (int)gridDim.x - 1) ? 1 : 0;
+  __syncthreads();
+  if (s_last) __threadfence();          // acquire: the other workgroups' rows
+  return s_last != 0;
+}
+
+// what the last workgroup of pass 1 does (256 threads): scan of the block sums, moments in block order, the means
+__device__ __forceinline__ void get_fold1(const cmbpo_rollout_t &r, int nblk, int32_t *offs, double *st) {
+  __shared__ int sm_i[17];
+  const int tid = threadIdx.x;
+  int carry = 0;
+  for (int base = 0; base < nblk; base += 256) {
+    const int c = base + tid;
+    const int v = c < nblk ? (int)__builtin_nontemporal_load(&r.store_part[(size_t)c * 8 + 5]) : 0;
+    int tot;
+    const int excl = block_excl_scan(v, sm_i, &tot);
+    if (c < nblk) r.store_part[(size_t)c * 8 + 6] = (double)(carry + excl);
+    carry += tot;
+  }
+  if (tid < 64) {
+    double acc[5];
+    for (int k = 0; k < 5; ++k) {
+      double a = 0.0;
+      for (int i = tid; i < nblk; i += 64) a += __builtin_nontemporal_load(&r.store_part[(size_t)i * 8 + k]);
+      acc[k] = wave_sum(a);
+    }
+    if (tid == 0) {
+      const double n = acc[0];
+      offs[r.B] = carry;
+      for (int k = 0; k < 5; ++k) st[8 + k] = acc[k];
+      st[13] = 0.0; st[2] = 0.0;
+      st[0] = n;
+      st[1] = n > 0 ? acc[1] / n : 0.0;
+      st[3] = n > 0 ? acc[2] / n : 0.0;
+      st[4] = n > 0 ? acc[3] / n : 0.0;
+      st[5] = n > 0 ? acc[4] / n : 0.0;
+    }
+  }
+}
+__device__ __forceinline__ void get_fold2(const cmbpo_rollout_t &r, int nblk, double *st) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    double a = 0.0;
+    for (int i = tid; i < nblk; i += 64) a += __builtin_nontemporal_load(&r.store_part[(size_t)i * 8 + 7]);
+    a = wave_sum(a);
+    if (tid == 0) {
+      const double n = st[8];
+      st[13] = a;
+      st[2] = n > 0 ? sqrt(a / n) : 0.0;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void get_fold_kernel(const cmbpo_rollout_t r, int pass, int nblk, int32_t *offs, double *st) {
+  if (pass == 1) get_fold1(r, nblk, offs, st);
+  else get_fold2(r, nblk, st);
+}
+
+// fold_here: the last workgroup to arrive folds (few workgroups: the returning atomics of hundreds of workgroups on one
+// counter serialise at the memory side, ~50 ns each -- then a one-workgroup launch of get_fold_kernel is cheaper)
+__global__ __launch_bounds__(256) void get_pass1_kernel(const cmbpo_rollout_t r, int32_t *offs, double *st, int fold_here) {
+  __shared__ double sm_d[16];
+  __shared__ int sm_i[17];
+  const size_t B = (size_t)r.B;
+  const int tid = threadIdx.x, b = blockIdx.x * 256 + tid;
+  const int L = b < r.B ? r.len[b] : 0;
+  double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+  for (int t = 0; t < L; ++t) {
+    const size_t o = (size_t)t * B + b;
+    s1 += r.adv_buf[o]; s2 += r.cadv_buf[o]; s3 += r.ret_buf[o]; s4 += r.cret_buf[o];
+  }
+  int total;
+  (void)block_excl_scan(L, sm_i, &total);
+  const double a1 = block_sum(s1, sm_d), a2 = block_sum(s2, sm_d), a3 = block_sum(s3, sm_d), a4 = block_sum(s4, sm_d);
+  double *part = r.store_part + (size_t)blockIdx.x * 8;
+  if (tid == 0) { part[0] = (double)total; part[1] = a1; part[2] = a2; part[3] = a3; part[4] = a4; part[5] = (double)total; }
+  if (!fold_here || !last_block_arrives(&r.iscal[30])) return;
+  get_fold1(r, gridDim.x, offs, st);
+  if (tid == 0) r.iscal[30] = 0;        // ready for the next get()
+}
+
+__global__ __launch_bounds__(256) void get_pass2_kernel(const cmbpo_rollout_t r, int32_t *offs, double *st, int fold_here) {
+  __shared__ double sm_d[16];
+  __shared__ int sm_i[17];
+  const size_t B = (size_t)r.B;
+  const int tid = threadIdx.x, b = blockIdx.x * 256 + tid;
+  const int L = b < r.B ? r.len[b] : 0;
+  const float mean = (float)st[1];
+  double s0 = 0;
+  for (int t = 0; t < L; ++t) {
+    const float d = __fsub_rn(r.adv_buf[(size_t)t * B + b], mean);  // (x - mean)**2 in float32 (mpi_tools.py:86)
+    s0 += (double)__fmul_rn(d, d);
+  }
+  int total;
+  const int excl = block_excl_scan(L, sm_i, &total);
+  double *part = r.store_part + (size_t)blockIdx.x * 8;
+  if (b < r.B) offs[b] = (int)part[6] + excl;
+  const double a0 = block_sum(s0, sm_d);
+  if (tid == 0) part[7] = a0;
+  if (!fold_here || !last_block_arrives(&r.iscal[31])) return;
+  get_fold2(r, gridDim.x, st);
+  if (tid == 0) r.iscal[31] = 0;
+}
+
 // flatten: time-major [t][b][.] buffers -> the reference's branch-major / time-minor list (modelbuffer.py:212-218).
 // Both sides of the copy want long contiguous runs: in the buffers the rows of consecutive BRANCHES at one step are
 // adjacent, in the output the rows of consecutive STEPS of one branch are.  So a workgroup takes a tile of branches, reads
@@ -802,30 +916,40 @@ __device__ __forceinline__ void flat_vec_in(float *tile, const float *src, int d
   }
 }
 
-// LDS -> output: branch bl's samples are tile[bl * T * dim ...] for len * dim floats, at dst + (offs - o0) * dim
-__device__ __forceinline__ void flat_vec_out(const float *tile, float *dst, int dim, int nb, int T, int cnt, int o0, const int *lens,
-                                             const int *loffs, int lane, int wave, int tid) {
-  if (cnt == nb * T) {                      // every path full: the tile is already the output block
-    const int n = cnt * dim;
+// LDS -> output: the tile's samples form ONE contiguous block of the output (branch-major: the runs of consecutive
+// branches are adjacent); sample p of the block is step t of branch bl, smap[p] = bl * T + t.  Every path full: the tile
+// already is the block.  Ragged paths: the block is written element by element in output order (consecutive lanes on
+// consecutive addresses whatever the path lengths are -- one short run per branch and wave left an 'uncertainty' rollout's
+// get() at 0.1 of the HBM rate).
+__device__ __forceinline__ void flat_vec_out(const float *tile, float *dst, int dim, int nb, int T, int cnt, int o0,
+                                             const unsigned short *smap, int tid) {
+  const int n = cnt * dim;
+  if (cnt == nb * T) {
     if ((((size_t)o0 * dim) & 3) == 0 && (n & 3) == 0) {
       for (int e = 4 * tid; e < n; e += 1024) *reinterpret_cast<f32x4 *>(dst + e) = *reinterpret_cast<const f32x4 *>(tile + e);
     } else {
       for (int e = tid; e < n; e += 256) dst[e] = tile[e];
     }
   } else {
-    for (int bl = wave; bl < nb; bl += 4) {
-      const float *tl = tile + (size_t)bl * T * dim;
-      float *d = dst + (size_t)(loffs[bl] - o0) * dim;
-      const int n = lens[bl] * dim;
-      for (int e = lane; e < n; e += 64) d[e] = tl[e];
+    const float inv = 1.0f / (float)dim;
+    for (int e = tid; e < n; e += 256) {
+      int p = (int)(((float)e + 0.5f) * inv);       // e / dim (exact: e < 2^18)
+      p -= (p * dim > e) ? 1 : 0;
+      p += ((p + 1) * dim <= e) ? 1 : 0;
+      dst[e] = tile[(int)smap[p] * dim + (e - p * dim)];
     }
   }
 }
 
 __global__ __launch_bounds__(256) void flatten_vec_kernel(const cmbpo_rollout_t r, const int32_t *offs, const FlatArgs fa,
-                                                          int vt) {
-  extern __shared__ float tile[];          // [vt][T][obs_dim], then [3][vt][T][act_dim]; vt <= kVecTile branches
+                                                          int vt, int Tt) {
+  // Tt = the steps the rollout took (<= r.T): no path is longer, so the tiles are laid out -- and the LDS sized -- for Tt
+  // steps (an 'uncertainty' rollout that ended after 5 of 34 steps: 9 KB per workgroup instead of 63, eight workgroups
+  // per CU instead of two)
+  extern __shared__ float tile[];          // [vt][Tt][obs_dim], then [3][vt][Tt][act_dim]; vt <= kVecTile branches
   __shared__ int lens[kVecTile], loffs[kVecTile + 1];
+  // (behind the tiles: output position inside the tile's block -> bl * Tt + t, vt * Tt entries)
+  unsigned short *smap = reinterpret_cast<unsigned short *>(tile + (size_t)vt * Tt * max(r.obs_dim, 3 * r.act_dim));
   const int b0 = blockIdx.x * vt;
   const int nb = min(r.B - b0, vt);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -837,12 +961,18 @@ __global__ __launch_bounds__(256) void flatten_vec_kernel(const cmbpo_rollout_t 
   int lmax = 0;
   for (int i = 0; i < nb; ++i) lmax = max(lmax, lens[i]);
   const size_t B = (size_t)r.B;
-  const int T = r.T, D = r.obs_dim, A = r.act_dim;
+  const int T = Tt, D = r.obs_dim, A = r.act_dim;
+  if (cnt != nb * T) {
+    for (int e = tid; e < nb * T; e += 256) {
+      const int bl = e / T, t = e - bl * T;
+      if (t < lens[bl]) smap[loffs[bl] - o0 + t] = (unsigned short)e;
+    }
+  }
   constexpr int NU = 9;                       // 4 waves x 9 steps: T <= 36 in one pass
   // obs (output 0)
   flat_vec_in<NU>(tile, r.obs_buf + (size_t)b0 * D, D, nb, T, lmax, B, lane, wave, tid);
   __syncthreads();
-  flat_vec_out(tile, fa.out[0] + (size_t)o0 * D, D, nb, T, cnt, o0, lens, loffs, lane, wave, tid);
+  flat_vec_out(tile, fa.out[0] + (size_t)o0 * D, D, nb, T, cnt, o0, smap, tid);
   __syncthreads();
   // act (1), log_std (10), mu (11): three tiles side by side
   const size_t ts = (size_t)vt * T * A;
@@ -850,25 +980,28 @@ __global__ __launch_bounds__(256) void flatten_vec_kernel(const cmbpo_rollout_t 
   flat_vec_in<NU>(tile + ts, r.ls_buf + (size_t)b0 * A, A, nb, T, lmax, B, lane, wave, tid);
   flat_vec_in<NU>(tile + 2 * ts, r.mu_buf + (size_t)b0 * A, A, nb, T, lmax, B, lane, wave, tid);
   __syncthreads();
-  flat_vec_out(tile, fa.out[1] + (size_t)o0 * A, A, nb, T, cnt, o0, lens, loffs, lane, wave, tid);
-  flat_vec_out(tile + ts, fa.out[10] + (size_t)o0 * A, A, nb, T, cnt, o0, lens, loffs, lane, wave, tid);
-  flat_vec_out(tile + 2 * ts, fa.out[11] + (size_t)o0 * A, A, nb, T, cnt, o0, lens, loffs, lane, wave, tid);
+  flat_vec_out(tile, fa.out[1] + (size_t)o0 * A, A, nb, T, cnt, o0, smap, tid);
+  flat_vec_out(tile + ts, fa.out[10] + (size_t)o0 * A, A, nb, T, cnt, o0, smap, tid);
+  flat_vec_out(tile + 2 * ts, fa.out[11] + (size_t)o0 * A, A, nb, T, cnt, o0, smap, tid);
 }
 
+// ROWS branches per workgroup: 64 (16 lanes x 16 bytes cover a step's row of the tile), or 16 for buffers too small to give
+// every CU a 64-branch tile (10 000 branches are 157 tiles of 64 on 256 CUs)
+template <int ROWS>
 __global__ __launch_bounds__(256) void flatten_scalar_kernel(const cmbpo_rollout_t r, const int32_t *offs, const double *st,
-                                                             const FlatArgs fa) {
-  extern __shared__ float tile[];          // [8][kFlatRows][T + 1] | position map [kFlatRows * T] (ushort)
-  __shared__ int loffs[kFlatRows + 1];
-  const int b0 = blockIdx.x * kFlatRows;
-  const int nb = min(r.B - b0, kFlatRows);
+                                                             const FlatArgs fa, int Tt) {
+  extern __shared__ float tile[];          // [8][ROWS][Tt + 1] | position map [ROWS * Tt] (ushort)
+  __shared__ int loffs[ROWS + 1];
+  const int b0 = blockIdx.x * ROWS;
+  const int nb = min(r.B - b0, ROWS);
   const int tid = threadIdx.x;
-  if (tid <= kFlatRows) loffs[tid] = offs[min(b0 + tid, r.B)];
+  if (tid <= ROWS) loffs[tid] = offs[min(b0 + tid, r.B)];
   __syncthreads();
   const int o0 = loffs[0], cnt = loffs[nb] - o0;
   if (cnt == 0) return;
   const size_t B = (size_t)r.B;
-  const int T = r.T, TS = T + 1;
-  const size_t fs = (size_t)kFlatRows * TS;          // floats of one field's tile
+  const int T = Tt, TS = T + 1;
+  const size_t fs = (size_t)ROWS * TS;               // floats of one field's tile
   unsigned short *map = reinterpret_cast<unsigned short *>(tile + 8 * fs);   // output position -> bl * TS + t
   int lmax = 0;
   for (int e = tid; e < nb * T; e += 256) {
@@ -879,36 +1012,36 @@ __global__ __launch_bounds__(256) void flatten_scalar_kernel(const cmbpo_rollout
   const float adv_mean = (float)st[1], adv_den = (float)st[2] + 1e-8f, cadv_mean = (float)st[3];
   // adv 2, cadv 3, ret 4, cret 5, logp 6, val 7, cval 8, cost 9: all eight fields in one pass
   const float *ssrc[8] = {r.adv_buf, r.cadv_buf, r.ret_buf, r.cret_buf, r.logp_buf, r.val_buf, r.cval_buf, r.cost_buf};
-  if (nb == kFlatRows && (B & 3) == 0) {
-    // 16 lanes x 16 bytes = the tile's 64 branches of one step; steps ts, ts + 16, ...; every load of a pass of 48 steps
-    // is requested before the first LDS write
-    const int l16 = tid & 15, ts = tid >> 4;
-    constexpr int NUS = 3;
-    for (int tb = ts; tb < lmax; tb += 16 * NUS) {
+  if (nb == ROWS && (B & 3) == 0) {
+    // LPS lanes x 16 bytes = the tile's branches of one step; steps ts, ts + G, ...; every load of a pass is requested
+    // before the first LDS write
+    constexpr int LPS = ROWS / 4, G = 256 / LPS, NUS = ROWS == 64 ? 3 : 1;
+    const int l16 = tid % LPS, ts = tid / LPS;
+    for (int tb = ts; tb < lmax; tb += G * NUS) {
       f32x4 v[8][NUS];
 #pragma unroll
       for (int g = 0; g < 8; ++g)
 #pragma unroll
         for (int u = 0; u < NUS; ++u) {
-          const int t = min(tb + 16 * u, T - 1);
+          const int t = min(tb + G * u, T - 1);
           v[g][u] = *reinterpret_cast<const f32x4 *>(ssrc[g] + (size_t)t * B + b0 + 4 * l16);
         }
 #pragma unroll
       for (int g = 0; g < 8; ++g)
 #pragma unroll
         for (int u = 0; u < NUS; ++u)
-          if (tb + 16 * u < lmax) {
-            float *tl = tile + g * fs + (4 * l16) * TS + tb + 16 * u;
+          if (tb + G * u < lmax) {
+            float *tl = tile + g * fs + (4 * l16) * TS + tb + G * u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) tl[i * TS] = v[g][u][i];
           }
     }
   } else {
-    const int bl_in = tid & 63, tq = tid >> 6;        // lanes over branches, waves over steps
+    const int bl_in = tid % ROWS, tq = tid / ROWS;    // lanes over branches, the rest over steps
     for (int g = 0; g < 8; ++g) {
       const float *src = ssrc[g] + b0 + min(bl_in, nb - 1);
       float *tl = tile + g * fs + bl_in * TS;
-      for (int t = tq; t < lmax; t += 4) {
+      for (int t = tq; t < lmax; t += 256 / ROWS) {
         const float x = src[(size_t)t * B];
         if (bl_in < nb) tl[t] = x;
       }
@@ -1119,6 +1252,22 @@ extern "C" int cmbpo_buffer_moments(const cmbpo_rollout_t *r, int pass, double *
   return CMBPO_OK;
 }
 
+extern "C" int cmbpo_buffer_prepare(const cmbpo_rollout_t *r, int32_t *d_offsets, double *d_stats, void *stream) {
+  if (int rc = check_rollout(r, "cmbpo_buffer_prepare")) return rc;
+  CMBPO_REQUIRE(d_offsets && d_stats, "cmbpo_buffer_prepare: NULL argument");
+  CMBPO_REQUIRE(r->world <= 1, "cmbpo_buffer_prepare: a sharded buffer needs the all-reduce between the passes "
+                               "(cmbpo_buffer_offsets / cmbpo_buffer_moments)");
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = cmbpo_ceil_div(r->B, 256);      // one partial row each: <= ceil(B / 64) rows exist
+  const int fold_here = blocks <= 128 ? 1 : 0;
+  hipLaunchKernelGGL(get_pass1_kernel, dim3(blocks), dim3(256), 0, s, *r, d_offsets, d_stats, fold_here);
+  if (!fold_here) hipLaunchKernelGGL(get_fold_kernel, dim3(1), dim3(256), 0, s, *r, 1, blocks, d_offsets, d_stats);
+  hipLaunchKernelGGL(get_pass2_kernel, dim3(blocks), dim3(256), 0, s, *r, d_offsets, d_stats, fold_here);
+  if (!fold_here) hipLaunchKernelGGL(get_fold_kernel, dim3(1), dim3(256), 0, s, *r, 2, blocks, d_offsets, d_stats);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
 extern "C" int cmbpo_buffer_flatten(const cmbpo_rollout_t *r, const int32_t *d_offsets, const double *d_stats,
                                     float *const *h_out12, void *stream) {
   if (int rc = check_rollout(r, "cmbpo_buffer_flatten")) return rc;
@@ -1130,15 +1279,26 @@ extern "C" int cmbpo_buffer_flatten(const cmbpo_rollout_t *r, const int32_t *d_o
   }
   hipStream_t s = (hipStream_t)stream;
   const int dmax = r->obs_dim > r->act_dim ? r->obs_dim : r->act_dim;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  // no path is longer than the steps the rollout took: tiles (and their LDS) are sized for those
+  const int Tt = r->ptr > 0 ? r->ptr : 1;
   // branches per workgroup of the vector fields: as many as keep the [branch][step][dim] tile within 64 KB (two
-  // workgroups per CU), 16 at AntSafe shapes and 34 steps
+  // workgroups per CU; 16 at AntSafe shapes and 34 steps), fewer while the buffer has less than four tiles per CU
   static const int vt_max = getenv("CMBPO_FLAT_VT") ? atoi(getenv("CMBPO_FLAT_VT")) : kVecTile;
   int vt = vt_max < 1 ? 1 : (vt_max > kVecTile ? kVecTile : vt_max);
   const int dtile = dmax > 3 * r->act_dim ? dmax : 3 * r->act_dim;     // obs alone, then act | log_std | mu side by side
-  while (vt > 1 && (size_t)vt * r->T * dtile * sizeof(float) > 64 * 1024) vt >>= 1;
-  const size_t lds_v = (size_t)vt * r->T * dtile * sizeof(float);
-  const size_t lds_s = (size_t)8 * kFlatRows * (r->T + 1) * sizeof(float) + (size_t)kFlatRows * r->T * sizeof(unsigned short);
-  CMBPO_REQUIRE(lds_v <= 150 * 1024 && lds_s <= 150 * 1024, "cmbpo_buffer_flatten: T = %d, dim = %d exceed the LDS tiles", r->T, dmax);
+  while (vt > 1 && (size_t)vt * Tt * dtile * sizeof(float) > 64 * 1024) vt >>= 1;
+  while (vt > 4 && cmbpo_ceil_div(r->B, vt) < 4 * n_cu) vt >>= 1;
+  const int rows = cmbpo_ceil_div(r->B, kFlatRows) < 2 * n_cu ? 16 : kFlatRows;
+  const size_t lds_v = (size_t)vt * Tt * dtile * sizeof(float) + (((size_t)vt * Tt * sizeof(unsigned short) + 15) & ~(size_t)15);
+  const size_t lds_s = (size_t)8 * rows * (Tt + 1) * sizeof(float) + (size_t)rows * Tt * sizeof(unsigned short);
+  CMBPO_REQUIRE(lds_v <= 150 * 1024 && lds_s <= 150 * 1024, "cmbpo_buffer_flatten: T = %d, dim = %d exceed the LDS tiles", Tt, dmax);
   static size_t attr_v = 64 * 1024, attr_s = 64 * 1024;
   if (lds_v > attr_v) {
     CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(flatten_vec_kernel),
@@ -1146,12 +1306,18 @@ extern "C" int cmbpo_buffer_flatten(const cmbpo_rollout_t *r, const int32_t *d_o
     attr_v = lds_v;
   }
   if (lds_s > attr_s) {
-    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(flatten_scalar_kernel),
+    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(flatten_scalar_kernel<kFlatRows>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(flatten_scalar_kernel<16>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
     attr_s = lds_s;
   }
-  hipLaunchKernelGGL(flatten_vec_kernel, dim3(cmbpo_ceil_div(r->B, vt)), dim3(256), lds_v, s, *r, d_offsets, fa, vt);
-  hipLaunchKernelGGL(flatten_scalar_kernel, dim3(cmbpo_ceil_div(r->B, kFlatRows)), dim3(256), lds_s, s, *r, d_offsets, d_stats, fa);
+  hipLaunchKernelGGL(flatten_vec_kernel, dim3(cmbpo_ceil_div(r->B, vt)), dim3(256), lds_v, s, *r, d_offsets, fa, vt, Tt);
+  if (rows == 16)
+    hipLaunchKernelGGL(flatten_scalar_kernel<16>, dim3(cmbpo_ceil_div(r->B, 16)), dim3(256), lds_s, s, *r, d_offsets, d_stats, fa, Tt);
+  else
+    hipLaunchKernelGGL(flatten_scalar_kernel<kFlatRows>, dim3(cmbpo_ceil_div(r->B, kFlatRows)), dim3(256), lds_s, s, *r, d_offsets,
+                       d_stats, fa, Tt);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }

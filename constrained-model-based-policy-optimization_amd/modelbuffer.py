@@ -225,20 +225,30 @@ class ModelBuffer:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
                   torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        self._call("cmbpo_buffer_offsets", t["offsets"].data_ptr())
-        self._call("cmbpo_buffer_moments", 0, t["stats"].data_ptr())
-        if self.comm is not None and self.comm.world > 1:
+        sharded = self.comm is not None and self.comm.world > 1
+        if sharded:
+            self._call("cmbpo_buffer_offsets", t["offsets"].data_ptr())
+            self._call("cmbpo_buffer_moments", 0, t["stats"].data_ptr())
             self.comm.all_reduce_sum(t["stats"][8:13])
-        self._call("cmbpo_buffer_moments", 1, t["stats"].data_ptr())
-        self._call("cmbpo_buffer_moments", 2, t["stats"].data_ptr())
-        if self.comm is not None and self.comm.world > 1:
+            self._call("cmbpo_buffer_moments", 1, t["stats"].data_ptr())
+            self._call("cmbpo_buffer_moments", 2, t["stats"].data_ptr())
             self.comm.all_reduce_sum(t["stats"][13:14])
-        self._call("cmbpo_buffer_moments", 3, t["stats"].data_ptr())
-        n = int(t["offsets"][self.batch_size].item())
+            self._call("cmbpo_buffer_moments", 3, t["stats"].data_ptr())
+        else:
+            # one GPU: the scan and both moment passes as two launches
+            self._call("cmbpo_buffer_prepare", t["offsets"].data_ptr(), t["stats"].data_ptr())
+        # the number of stored samples is the pool's size counter, read with the step counters: no device round trip here
+        n = int(self._size)
         D, A, dev = self.obs_dim, self.act_dim, self.device
-        f = dict(dtype=torch.float32, device=dev)
         dims = [D, A, 0, 0, 0, 0, 0, 0, 0, 0, A, A]
-        outs = [torch.empty((n, d) if d else (n,), **f) for d in dims]
+        # one allocation for the twelve arrays (each starts on a 256-byte boundary) and one split: the list holds views of it
+        sizes = []
+        for d in dims:
+            m = n * max(d, 1)
+            sizes += [m, -m % 64]
+        flat = torch.empty(max(sum(sizes), 1), dtype=torch.float32, device=dev)
+        parts = flat.split_with_sizes(sizes)[0::2] if n > 0 else [flat[:0]] * 12
+        outs = [p_.view(n, d) if d else p_ for p_, d in zip(parts, dims)]
         if n > 0:
             ptrs = (C.c_void_p * 12)(*[o.data_ptr() for o in outs])
             if ev is not None:

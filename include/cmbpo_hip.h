@@ -316,6 +316,12 @@ int cmbpo_rollout_run(cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy, cmbp
  * (global statistics after an all-reduce) NULL the local ones are used. */
 int cmbpo_buffer_offsets(const cmbpo_rollout_t *r, int32_t *d_offsets, void *stream);
 int cmbpo_buffer_moments(const cmbpo_rollout_t *r, int pass, double *d_stats, void *stream);
+/* The same offsets and statistics on ONE GPU as two launches (four beyond 32 768 branches, where the fold of the
+ * workgroups' partial sums is a launch of its own; r->world <= 1; replaces cmbpo_buffer_offsets + the four
+ * cmbpo_buffer_moments passes of ModelBuffer.get, buffers/modelbuffer.py:184-204 / utilities/mpi_tools.py:71-92): the
+ * scan of the path lengths and the first moments in one pass over the buffers, the offsets and the centred second
+ * moment in another; the last workgroup of each launch adds the workgroups' partial sums in a fixed order. */
+int cmbpo_buffer_prepare(const cmbpo_rollout_t *r, int32_t *d_offsets, double *d_stats, void *stream);
 /* Flatten in branch-major, time-minor order into the 12-array list
  * [obs, act, adv, cadv, ret, cret, logp, val, cval, cost, log_std, mu]
  * (modelbuffer.py:212-218), normalising adv by (mean, std + 1e-8) and centring

@@ -14,7 +14,7 @@ import cmbpo_amd  # noqa: F401
 from cmbpo_amd import synthetic
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-task = "AntSafe-v2"
+task = sys.argv[2] if len(sys.argv) > 2 else "AntSafe-v2"
 w = bench.build_world(0, task)
 dev = torch.device("cuda:0")
 sampler, pool, env, policy = bench.build_hip(w, task, B, dev)
@@ -39,6 +39,7 @@ def timed(fn, reps=5):
     return s.elapsed_time(e) / reps * 1e3
 
 
+us_prep = timed(lambda: pool._call("cmbpo_buffer_prepare", t["offsets"].data_ptr(), t["stats"].data_ptr()))
 us_off = timed(lambda: pool._call("cmbpo_buffer_offsets", t["offsets"].data_ptr()))
 us_m0 = timed(lambda: pool._call("cmbpo_buffer_moments", 0, t["stats"].data_ptr()))
 pool._call("cmbpo_buffer_moments", 1, t["stats"].data_ptr())
@@ -53,6 +54,7 @@ us_fl = timed(lambda: pool._call("cmbpo_buffer_flatten", t["offsets"].data_ptr()
 bytes_fl = 2.0 * 4.0 * n * (D + 3 * A + 8)
 print(f"samples {n}: offsets {us_off:.1f} us, moments pass0 {us_m0:.1f} us, pass2 {us_m2:.1f} us, flatten {us_fl:.1f} us "
       f"= {bytes_fl / us_fl / 1e6:.2f} TB/s ({bytes_fl / 1e6:.0f} MB algorithmic)")
+print(f"one-GPU path: prepare (scan + both moment passes, two launches) {us_prep:.1f} us; with flatten {us_prep + us_fl:.1f} us")
 tot = us_off + us_m0 + us_m2 + us_fl
 bytes_all = bytes_fl + 4.0 * n * (5 + 1)       # + the moment passes' reads
 print(f"get() kernels {tot:.1f} us, {bytes_all / tot / 1e6:.2f} TB/s over all of them")

@@ -169,6 +169,16 @@ __device__ __forceinline__ void static_for(F &&f) {
   }
 }
 
+// The item loop's barriers order LDS traffic only (images, partial sums, staging tiles; nothing stored to global memory is read
+// back inside the kernel).  __syncthreads() is a workgroup fence + s_barrier, in front of which hipcc waits vmcnt(0): for
+// every global access in flight -- the output stores of the previous unit (a write acknowledgement from HBM), the next
+// item's input rows and row indices, the weight fragments requested a slab ahead.  Draining the LDS counter is enough.
+#ifdef H3_FULL_BARRIERS      // diagnostic: round 2's barriers
+#define H3_BARRIER() __syncthreads()
+#else
+#define H3_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 #ifndef H3_TAIL_RING
 #define H3_TAIL_RING 0      // diagnostic: 1 = W2 fragments through the two-slab ring for every shape (round 2's tail)
 #endif
@@ -291,8 +301,8 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
           w0r[u] = w0e[(size_t)(j < 2 * W0P ? j : 0) * 64 + lane];
         }
       }
-      bias0[tid] = bpre[0];
-      bias1[tid] = bpre[1];
+      bias0[tid] = bpre[0] * kLog2e;      // (the epilogues work on z log2(e): epi_stage<.., PRE>)
+      bias1[tid] = bpre[1] * kLog2e;
       if (tid < O_PAD) {
         // y = A_n z + B_n with z = o + b2_n; n < out: mean = sig z + mu; out <= n < 2 out: var = exp(z + 2 log sig)
         // (models/pens/pe.py:815-835)
@@ -355,12 +365,12 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
     }
     fetch_row(item + gridDim.x, tid);     // the next item's row index: lands during the layers
     H3_STAMP(0);
-    __syncthreads();
+    H3_BARRIER();
     H3_STAMP(1);
 
     // ---- layers 0 + 1, fused over the 8 chunks of h1 -------------------------------------------------------------------
     const int l0_tn = wave & (NTC - 1), l0_bt = wave / NTC;     // this wave's (n-tile, row-tile) pair of every chunk
-    const float inv0_l = r_inv0[32 * l0_bt + r], t1_l = r_t1[32 * l0_bt + r];
+    const float inv0_l = r_inv0[32 * l0_bt + r] * kLog2e, t1_l = r_t1[32 * l0_bt + r] * kLn2;
     const _Float16 *xb0 = ximg + (size_t)(32 * l0_bt + r) * XSTR + 8 * hh;
     // layer-0 operands of one 16-deep slab: W0 fragments of the chunk (LDS copy) and this wave's rows of the x image
     struct L0Ops { f16x8 a1, a2, b1, b2; };
@@ -420,11 +430,11 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
       for (int q = 0; q < 4; ++q) {
         Epi4 es;
         const f32x4 bv = l0_bias(0, q);
-        epi_all<false>(es, d, q, inv0_l, bv, t1_l);
+        epi_all<false, true>(es, d, q, inv0_l, bv, t1_l);
         l0_store(es, 0, q);
       }
     }
-    __syncthreads();
+    H3_BARRIER();
     H3_STAMP(2);
 
     // One step = the 96 layer-1 MFMAs of chunk c -- 16 (slab, row tile) positions of 6, in 8 groups of 12 -- with the
@@ -493,16 +503,16 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
           if (slot >= 4) {
 #endif
             const int q = slot - 4;
-            if (i == 0) epi_stage<0, true>(es, d, q, inv0_l, bv, t1_l);
-            if (i == 1) epi_stage<1, true>(es, d, q, inv0_l, bv, t1_l);
-            if (i == 2) epi_stage<2, true>(es, d, q, inv0_l, bv, t1_l);
-            if (i == 3) epi_stage<3, true>(es, d, q, inv0_l, bv, t1_l);
-            if (i == 4) epi_stage<4, true>(es, d, q, inv0_l, bv, t1_l);
-            if (i == 5) epi_stage<5, true>(es, d, q, inv0_l, bv, t1_l);
-            if (i == 6) epi_stage<6, true>(es, d, q, inv0_l, bv, t1_l);
-            if (i == 7) epi_stage<7, true>(es, d, q, inv0_l, bv, t1_l);
-            if (i == 8) epi_stage<8, true>(es, d, q, inv0_l, bv, t1_l);
-            if (i == 9) epi_stage<9, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 0) epi_stage<0, true, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 1) epi_stage<1, true, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 2) epi_stage<2, true, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 3) epi_stage<3, true, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 4) epi_stage<4, true, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 5) epi_stage<5, true, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 6) epi_stage<6, true, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 7) epi_stage<7, true, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 8) epi_stage<8, true, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 9) epi_stage<9, true, true>(es, d, q, inv0_l, bv, t1_l);
             if (i == 10) l0_store(es, c + 1, q);
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -515,7 +525,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
           if (j < W0P) w0buf[((size_t)(c & 1) * W0P + j) * 64 + lane] = wst;
         }
       }
-      __syncthreads();
+      H3_BARRIER();
       H3_STAMP(5);
     }
 
@@ -534,7 +544,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
           for (int i = 0; i < 16; ++i) keep += acc[t][bt][i];
       if (keep == 123.456f) p.out0[0] = keep;
     }
-    __syncthreads();
+    H3_BARRIER();
     continue;
 #endif
 
@@ -593,25 +603,32 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
           w2r[S][tt][0] = q[0]; w2r[S][tt][1] = q[64];
         }
       });
-      static_for<0, RT>([&](auto RTI) {
+      // The tail as four stages per row tile, A: swish / lift / split of h2 (VALU) -> B: output-layer MFMAs + partial sums to
+      // LDS -> [barrier] -> C: sum of the eight waves' partials + head -> D: stores.  Between two barriers a wave runs
+      // D(k-2), C(k-1), B(k), A(k+1).  Measured (profiles/r03/h3_variants_5.log, _6.log): each stage costs about what its
+      // instructions cost alone (A 5.7 %, B 5.1 %, C + D 4.5 % of a forward); giving the two waves of a SIMD opposite orders
+      // inside an interval (-DH3_TAIL_STAGGER: waves 4-7 run A(k+1) first) or dealing A(k+1) out between B(k)'s MFMAs
+      // changed nothing (1.264 -> 1.269 ms), so the plain order stands.
+      u32x4 bfu[2][4][2];        // [row tile & 1][slab of this wave's K slice][piece]
+      auto stA = [&](auto RTI) {
         constexpr int rt = decltype(RTI)::value;
-        f16x8 bf[4][2];
-        {
-          u32x4 bfu[4][2];
-          const float inv1_l = r_inv1[32 * rt + r], t2_l = r_t2[32 * rt + r];
-          static_for<0, 8>([&](auto QD) {
-            constexpr int quad = decltype(QD)::value, S = quad >> 1, jq = quad & 1, q = 2 * (S & 1) + jq;
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias1 + 64 * wave + 32 * (S >> 1) + 8 * q + 4 * hh);
-            Epi4 es;
-            epi_all<false>(es, acc[S >> 1][rt], q, inv1_l, bv, t2_l);
-            bfu[S][0][2 * jq] = es.q1[0]; bfu[S][0][2 * jq + 1] = es.q1[1];
-            bfu[S][1][2 * jq] = es.q2[0]; bfu[S][1][2 * jq + 1] = es.q2[1];
-          });
-#pragma unroll
-          for (int S = 0; S < 4; ++S)
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc) bf[S][pc] = __builtin_bit_cast(f16x8, bfu[S][pc]);
-        }
+        const float inv1_l = r_inv1[32 * rt + r] * kLog2e, t2_l = r_t2[32 * rt + r] * kLn2;
+        static_for<0, 8>([&](auto QD) {
+          constexpr int quad = decltype(QD)::value, S = quad >> 1, jq = quad & 1, q = 2 * (S & 1) + jq;
+          const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias1 + 64 * wave + 32 * (S >> 1) + 8 * q + 4 * hh);
+          Epi4 es;
+#ifdef H3_DIAG_TAIL_NOA
+          es.q1[0] = __float_as_uint(acc[S >> 1][rt][4 * q] + bv[0]) & 0x3fff3fffu; es.q1[1] = __float_as_uint(acc[S >> 1][rt][4 * q + 1] + inv1_l) & 0x3fff3fffu;
+          es.q2[0] = __float_as_uint(acc[S >> 1][rt][4 * q + 2] + t2_l) & 0x3fff3fffu; es.q2[1] = __float_as_uint(acc[S >> 1][rt][4 * q + 3]) & 0x3fff3fffu;
+#else
+          epi_all<false, true>(es, acc[S >> 1][rt], q, inv1_l, bv, t2_l);
+#endif
+          bfu[rt & 1][S][0][2 * jq] = es.q1[0]; bfu[rt & 1][S][0][2 * jq + 1] = es.q1[1];
+          bfu[rt & 1][S][1][2 * jq] = es.q2[0]; bfu[rt & 1][S][1][2 * jq + 1] = es.q2[1];
+        });
+      };
+      auto stB = [&](auto RTI) {
+        constexpr int rt = decltype(RTI)::value;
         f32x16 o[2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
@@ -619,8 +636,14 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
           for (int i = 0; i < 16; ++i) o[tt][i] = 0.0f;
         static_for<0, 4>([&](auto SI) {
           constexpr int S = decltype(SI)::value;
+          const f16x8 b1 = __builtin_bit_cast(f16x8, bfu[rt & 1][S][0]), b2 = __builtin_bit_cast(f16x8, bfu[rt & 1][S][1]);
+#ifdef H3_DIAG_TAIL_NOB
 #pragma unroll
-          for (int tt = 0; tt < 2; ++tt) mm3(o[tt], w2r[S][tt][0], w2r[S][tt][1], bf[S][0], bf[S][1]);
+          for (int tt = 0; tt < 2; ++tt) { o[tt][S] += (float)b1[tt] + (float)w2r[S][tt][0][0]; o[tt][S + 4] += (float)b2[tt] + (float)w2r[S][tt][1][1]; }
+#else
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) mm3(o[tt], w2r[S][tt][0], w2r[S][tt][1], b1, b2);
+#endif
         });
         f32x4 *pw = pbuf + ((size_t)(rt & 1) * 64 + (size_t)wave * 8) * 64 + lane;
 #pragma unroll
@@ -630,12 +653,31 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
             const f32x4 v = {o[tt][4 * q], o[tt][4 * q + 1], o[tt][4 * q + 2], o[tt][4 * q + 3]};
             pw[(size_t)(tt * 4 + q) * 64] = v;
           }
+      };
+      stA(std::integral_constant<int, 0>{});
+      static_for<0, RT + 2>([&](auto KI) {
+        constexpr int k = decltype(KI)::value;      // interval k: D(k - 2), C(k - 1), B(k), A(k + 1)
+        auto matrix_side = [&]() {
+#ifndef H3_DIAG_TAIL_NOD
+          if constexpr (k >= 2 && k - 2 < RT) store_unit(k - 2);
+#endif
+#ifndef H3_DIAG_TAIL_NOC
+          if constexpr (k >= 1 && k - 1 < RT) reduce_unit(k - 1);
+#endif
+          if constexpr (k < RT) stB(std::integral_constant<int, (k < RT ? k : 0)>{});
+        };
+        auto valu_side = [&]() {
+          if constexpr (k + 1 < RT) stA(std::integral_constant<int, (k + 1 < RT ? k + 1 : 0)>{});
+        };
+#ifdef H3_TAIL_STAGGER      // diagnostic (from the second interval on: in the first it spills 45 registers)
+        if (k == 0 || wave < 4) { matrix_side(); valu_side(); }
+        else { valu_side(); matrix_side(); }
+#else
+        matrix_side(); valu_side();
+#endif
         H3_STAMP(7);
-        __syncthreads();       // unit rt's partials are complete; unit rt - 1's staging tile too
+        if constexpr (k + 1 < RT + 2) H3_BARRIER();
         H3_STAMP(8);
-        if (rt > 0) store_unit(rt - 1);
-        reduce_unit(rt);
-        H3_STAMP(9);
       });
     } else {
 #pragma unroll
@@ -653,7 +695,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
       f16x8 bf[4][2];
       {
         u32x4 bfu[4][2];
-        const float inv1_l = r_inv1[32 * rt + r], t2_l = r_t2[32 * rt + r];
+        const float inv1_l = r_inv1[32 * rt + r] * kLog2e, t2_l = r_t2[32 * rt + r] * kLn2;
 #pragma unroll
         for (int S = 0; S < 4; ++S)
 #pragma unroll
@@ -661,7 +703,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
             const int q = 2 * (S & 1) + jq;
             const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias1 + 64 * wave + 32 * (S >> 1) + 8 * q + 4 * hh);
             Epi4 es;
-            epi_all<false>(es, acc[S >> 1][rt], q, inv1_l, bv, t2_l);
+            epi_all<false, true>(es, acc[S >> 1][rt], q, inv1_l, bv, t2_l);
             bfu[S][0][2 * jq] = es.q1[0]; bfu[S][0][2 * jq + 1] = es.q1[1];
             bfu[S][1][2 * jq] = es.q2[0]; bfu[S][1][2 * jq + 1] = es.q2[1];
           }
@@ -694,18 +736,18 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
             pw[(size_t)(tt * 4 + q) * 64] = v;
           }
         H3_STAMP(7);
-        __syncthreads();       // unit u's partials are complete; unit u - 1's staging tile too
+        H3_BARRIER();       // unit u's partials are complete; unit u - 1's staging tile too
         H3_STAMP(8);
         if (u > 0) store_unit(u - 1);
         reduce_unit(u);
         H3_STAMP(9);
       }
     }
-    }
-    __syncthreads();
+    H3_BARRIER();
     store_unit(NUNIT - 1);
+    }
     H3_STAMP(10);
-    __syncthreads();     // the LDS regions are rewritten by the next item's stage
+    H3_BARRIER();     // the LDS regions are rewritten by the next item's stage
     H3_STAMP(11);
   }  // persistent item loop
 #ifdef CMBPO_STAMPS

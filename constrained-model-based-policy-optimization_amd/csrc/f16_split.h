@@ -61,9 +61,19 @@ struct Epi4 {
   float z[4], e[4];
   unsigned q1[2], q2[2];   // p1 / p2 of the four values, packed f16x2
 };
-template <int K, bool PIN>
+// PRE: the caller passes inv and the bias multiplied by log2(e) and the lift tn by ln 2 -- stage 0 then yields y = z log2(e),
+// the exponential reads -y through its source modifier (no separate multiply: 7 instead of 8 instructions per value), and
+// the split's exact product y sigma(z) (tn ln 2) is swish(z) tn up to the float rounding of log2(e) ln 2 (1 - 2e-8).
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+template <int K, bool PIN, bool PRE = false>
 __device__ __forceinline__ void epi_stage(Epi4 &s, const f32x16 &d, int q, float inv, const f32x4 &bv, float tn) {
-  if constexpr (K == 0) {
+  if constexpr (PRE && K == 1) {
+    // (nothing: the scaling is in inv / bv)
+  } else if constexpr (PRE && (K == 2 || K == 3)) {
+    constexpr int o = 2 * (K - 2);
+    s.e[o] = __builtin_amdgcn_exp2f(-s.z[o]); s.e[o + 1] = __builtin_amdgcn_exp2f(-s.z[o + 1]);
+    if (PIN) asm volatile("" : "+v"(s.e[o]), "+v"(s.e[o + 1]));
+  } else if constexpr (K == 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) s.z[i] = __builtin_fmaf(d[4 * q + i], inv, bv[i]);
     if (PIN) asm volatile("" : "+v"(s.z[0]), "+v"(s.z[1]), "+v"(s.z[2]), "+v"(s.z[3]));
@@ -115,12 +125,12 @@ __device__ __forceinline__ void epi_stage(Epi4 &s, const f32x16 &d, int q, float
     if (PIN) asm volatile("" : "+v"(s.q2[0]), "+v"(s.q2[1]));
   }
 }
-template <bool PIN>
+template <bool PIN, bool PRE = false>
 __device__ __forceinline__ void epi_all(Epi4 &s, const f32x16 &d, int q, float inv, const f32x4 &bv, float tn) {
-  epi_stage<0, PIN>(s, d, q, inv, bv, tn); epi_stage<1, PIN>(s, d, q, inv, bv, tn); epi_stage<2, PIN>(s, d, q, inv, bv, tn);
-  epi_stage<3, PIN>(s, d, q, inv, bv, tn); epi_stage<4, PIN>(s, d, q, inv, bv, tn); epi_stage<5, PIN>(s, d, q, inv, bv, tn);
-  epi_stage<6, PIN>(s, d, q, inv, bv, tn); epi_stage<7, PIN>(s, d, q, inv, bv, tn); epi_stage<8, PIN>(s, d, q, inv, bv, tn);
-  epi_stage<9, PIN>(s, d, q, inv, bv, tn);
+  epi_stage<0, PIN, PRE>(s, d, q, inv, bv, tn); epi_stage<1, PIN, PRE>(s, d, q, inv, bv, tn); epi_stage<2, PIN, PRE>(s, d, q, inv, bv, tn);
+  epi_stage<3, PIN, PRE>(s, d, q, inv, bv, tn); epi_stage<4, PIN, PRE>(s, d, q, inv, bv, tn); epi_stage<5, PIN, PRE>(s, d, q, inv, bv, tn);
+  epi_stage<6, PIN, PRE>(s, d, q, inv, bv, tn); epi_stage<7, PIN, PRE>(s, d, q, inv, bv, tn); epi_stage<8, PIN, PRE>(s, d, q, inv, bv, tn);
+  epi_stage<9, PIN, PRE>(s, d, q, inv, bv, tn);
 }
 
 

@@ -114,10 +114,11 @@ __device__ __forceinline__ void store_hidden(const f32x16 (&acc)[NT][BT],
 // wave's [n-slice x BB rows] tile go to the export arrays [row][HID] as float4 groups of four consecutive n.
 // `grow` = first export row of the tile (member offset included), rows at or beyond `n_valid` are not written.
 template <int NT, int BT, int HID, bool TO_LDS>
-__device__ __forceinline__ void hidden_train(f32x16 (&acc)[NT][BT], int n_base, f32x4 *lds_out, int lane,
-                                             float *__restrict__ eh, float *__restrict__ eg, size_t grow, int n_valid) {
+__device__ __forceinline__ float hidden_train(f32x16 (&acc)[NT][BT], int n_base, f32x4 *lds_out, int lane,
+                                              float *__restrict__ eh, float *__restrict__ eg, size_t grow, int n_valid) {
   constexpr int BB = 32 * BT;
   const int j = lane & 31, h = lane >> 5;
+  float hmax = 0.0f;      // largest |h| among the rows this lane exports
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int n0 = n_base + t * 32;
@@ -140,10 +141,12 @@ __device__ __forceinline__ void hidden_train(f32x16 (&acc)[NT][BT], int n_base, 
           const size_t o = (grow + b) * HID + n;
           *reinterpret_cast<f32x4 *>(eh + o) = hv;
           *reinterpret_cast<f32x4 *>(eg + o) = gv;
+          hmax = fmaxf(fmaxf(hmax, fmaxf(fabsf(hv[0]), fabsf(hv[1]))), fmaxf(fabsf(hv[2]), fabsf(hv[3])));
         }
       }
     }
   }
+  return hmax;
 }
 
 // activation in place: the accumulator tile becomes the B operand of the output layer.
@@ -268,6 +271,8 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
   // ---- stage the (scaled) input tile: xT[k][b], k = [obs | act] ------------
   // 8 threads per branch row; every thread issues all of its (independent) global loads before it
   // touches LDS, so the prologue pays the memory latency once instead of once per element.
+  __shared__ float s_opmax[3][kWaves];     // HEAD_TRAIN: per-wave maxima of |x|, |h1|, |h2| of this tile
+  float xmax_t = 0.0f;
   {
     float *xf = reinterpret_cast<float *>(xbuf);
     const int c = tid & 7;
@@ -305,7 +310,10 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
             }
             xf[((k >> 2) * BB + b) * 4 + (k & 3)] = x;   // k >= in_dim: zero padding
             if constexpr (HEAD == CMBPO_HEAD_TRAIN) {
-              if (p.tr_x && r >= 0) p.tr_x[((size_t)chunk * n_rows + row0 + b) * p.in_pad + k] = x;
+              if (p.tr_x && r >= 0) {
+                p.tr_x[((size_t)chunk * n_rows + row0 + b) * p.in_pad + k] = x;
+                xmax_t = fmaxf(xmax_t, fabsf(x));
+              }
             }
           }
         }
@@ -313,6 +321,11 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
     }
   }
 
+  if constexpr (HEAD == CMBPO_HEAD_TRAIN) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) xmax_t = fmaxf(xmax_t, __shfl_xor(xmax_t, o, 64));
+    if (lane == 0) s_opmax[0][wave] = xmax_t;      // (read in the head epilogue, several barriers on)
+  }
   const int e_begin = chunk * p.e_chunk;
   const int e_end = min(p.ensemble, e_begin + p.e_chunk);
   float member_sum = 0.0f;  // HEAD_DETMEAN: running sum over members
@@ -340,10 +353,13 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
       const f32x4 *wp = p.wp0 + e * p.wp0_stride + (size_t)(wave * NT) * kg0 * 64;
       mfma_layer<NT, BT>(wp, (size_t)kg0 * 64, 0, kg0, xbuf, lane, acc);
       STAMP(2);
-      if constexpr (HEAD == CMBPO_HEAD_TRAIN)
-        hidden_train<NT, BT, HID, true>(acc, wave * NT * 32, hbuf, lane, p.tr_h1, p.tr_g1,
-                                        (size_t)e * n_rows + row0, n_rows - row0);
-      else
+      if constexpr (HEAD == CMBPO_HEAD_TRAIN) {
+        float hm = hidden_train<NT, BT, HID, true>(acc, wave * NT * 32, hbuf, lane, p.tr_h1, p.tr_g1,
+                                                   (size_t)e * n_rows + row0, n_rows - row0);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) hm = fmaxf(hm, __shfl_xor(hm, o, 64));
+        if (lane == 0) s_opmax[1][wave] = hm;
+      } else
         store_hidden<NT, BT, ACT>(acc, wave * NT * 32, hbuf, lane);
     }
     __syncthreads();
@@ -357,10 +373,13 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
       // ~27-cycle issue cost of each global_load_dwordx4 next to the MFMAs, not exposed latency)
       mfma_layer<NT, BT>(wp, (size_t)KG_H * 64, 0, KG_H, hbuf, lane, acc);
       STAMP(4);
-      if constexpr (HEAD == CMBPO_HEAD_TRAIN)
-        hidden_train<NT, BT, HID, false>(acc, wave * NT * 32, nullptr, lane, p.tr_h2, p.tr_g2,
-                                         (size_t)e * n_rows + row0, n_rows - row0);
-      else
+      if constexpr (HEAD == CMBPO_HEAD_TRAIN) {
+        float hm = hidden_train<NT, BT, HID, false>(acc, wave * NT * 32, nullptr, lane, p.tr_h2, p.tr_g2,
+                                                    (size_t)e * n_rows + row0, n_rows - row0);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) hm = fmaxf(hm, __shfl_xor(hm, o, 64));
+        if (lane == 0) s_opmax[2][wave] = hm;
+      } else
         activate_regs<NT, BT, ACT>(acc);   // h2 slice of this wave
       STAMP(5);
       __syncthreads();  // every wave has finished reading h1: hbuf becomes the reduction image
@@ -435,6 +454,8 @@ __global__ __launch_bounds__(kThreads, (BT == 1 ? 2 : 1)) void ens_mlp_kernel(
       }
     } else if constexpr (HEAD == CMBPO_HEAD_TRAIN) {
       // raw network output (no output scaler, no exp): models/pens/pe.py:803-812 with ret_log_var
+      if (p.tr_opmax && tid < 3)
+        p.tr_opmax[(size_t)item * 8 + tid] = fmaxf(fmaxf(s_opmax[tid][0], s_opmax[tid][1]), fmaxf(s_opmax[tid][2], s_opmax[tid][3]));
       const int ow = p.o_width;
       for (int i = tid; i < BB * ow; i += kThreads) {
         const int b = i / ow, n = i - b * ow;

@@ -45,6 +45,8 @@ struct MlpKernelArgs {
   const float *tr_targets;     // [N][tr_tdim] regression targets (rows gathered like the inputs); with tr_loss_part
   int tr_tdim;
   double *tr_loss_part;        // [items][3] per-tile loss statistics (nullptr: not wanted)
+  float *tr_opmax;             // [items][8] largest |x|, |h1|, |h2| of the tile in slots 0..2 (nullptr: not wanted): the
+                               // f16 weight-gradient kernel lifts its operands by the member's maxima (ens_train.hip)
 };
 
 struct cmbpo_mlp {

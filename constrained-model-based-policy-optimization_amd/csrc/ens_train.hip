@@ -19,6 +19,7 @@
 // fused kernel instead (fused_mse_step_kernel).
 #include "common.h"
 #include "ens_mlp_internal.h"
+#include "f16_split.h"
 #include "mfma_tile.h"
 #include "row_tile.h"
 
@@ -114,6 +115,7 @@ struct BwdArgs {
   int idx_stride;
   const double *loss_part;   // [n_items][3]
   float *d3_out;             // [E][B][OPk], written for the weight-gradient kernel
+  float *opmax;              // [E * tiles][8]: largest |d1|, |d2|, |d3| of the tile into slots 3..5 (nullptr: not wanted)
 };
 
 template <int HID>
@@ -125,6 +127,8 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdArgs p)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int e = blockIdx.y, row0 = blockIdx.x * BB;
   const int kgo = p.OPk / 8;
+  __shared__ float s_dmax[3][kThreads / 64];   // per-wave maxima of |d3|, |d2|, |d1| of this tile
+  float dmax = 0.0f;
   if (!p.fuse) {
     float *xf = reinterpret_cast<float *>(xbuf);
     for (int i = tid; i < BB * p.OPk; i += kThreads) {
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdArgs p)
       float v = 0.0f;
       if (row0 + b < p.B) v = p.d3[((size_t)e * p.B + row0 + b) * p.OPk + k];
       xf[((k >> 2) * BB + b) * 4 + (k & 3)] = v;
+      dmax = fmaxf(dmax, fabsf(v));
     }
   } else {
     // Output deltas d(train_loss)/d(raw output).
@@ -192,8 +197,16 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdArgs p)
         p.d3_out[((size_t)e * p.B + row) * p.OPk + k] = v;
       }
       xf[((k >> 2) * BB + b) * 4 + (k & 3)] = v;
+      dmax = fmaxf(dmax, fabsf(v));
     }
   }
+  auto wave_max_to = [&](float m, float *slot) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) slot[wave] = m;
+  };
+  wave_max_to(dmax, s_dmax[0]);
+  dmax = 0.0f;
   const int j = lane & 31, h = lane >> 5;
   const bool valid = row0 + j < p.B;
   const size_t grow = ((size_t)e * p.B + row0 + j) * HID;
@@ -230,8 +243,13 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdArgs p)
 #pragma unroll
       for (int s = 0; s < 4; ++s) v[s] = acc[t][0][4 * q + s] * gq[t][q][s];
       hbuf[(n >> 2) * BB + j] = v;
-      if (valid) *reinterpret_cast<f32x4 *>(p.d2 + grow + n) = v;
+      if (valid) {
+        *reinterpret_cast<f32x4 *>(p.d2 + grow + n) = v;
+        dmax = fmaxf(fmaxf(dmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      }
     }
+  wave_max_to(dmax, s_dmax[1]);
+  dmax = 0.0f;
   load_g(p.g1);
   zero_acc();
   __syncthreads();
@@ -244,8 +262,19 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdArgs p)
       f32x4 v;
 #pragma unroll
       for (int s = 0; s < 4; ++s) v[s] = acc[t][0][4 * q + s] * gq[t][q][s];
-      if (valid) *reinterpret_cast<f32x4 *>(p.d1 + grow + n) = v;
+      if (valid) {
+        *reinterpret_cast<f32x4 *>(p.d1 + grow + n) = v;
+        dmax = fmaxf(fmaxf(dmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      }
     }
+  if (p.opmax) {
+    wave_max_to(dmax, s_dmax[2]);
+    __syncthreads();
+    if (tid < 3) {
+      const float *sm = s_dmax[2 - tid];      // slots 3, 4, 5 = d1, d2, d3
+      p.opmax[((size_t)e * gridDim.x + blockIdx.x) * 8 + 3 + tid] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -268,7 +297,12 @@ struct WgradArgs {
   float *bias_out;             // [ks][E][bias_member]
   size_t bias_member, bias_part;
   int bias_mode, bias_n;
+  // f16 path: largest |value| of each operand per 32-row tile (left by the kernels that produce the arrays; a workgroup
+  // takes the maximum over its member's tiles)
+  const float *amax, *bmax;    // [E][max_tiles][kOpMax], already offset to this operand's slot
+  int max_tiles;
 };
+constexpr int kOpMax = 8;      // slots per tile: 0 x, 1 h1, 2 h2, 3 d1, 4 d2, 5 d3
 
 __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(const WgradArgs p) {
   extern __shared__ float red[];   // [2][128][64]
@@ -585,6 +619,227 @@ __device__ __forceinline__ void wgrad_lds_body(const WgradArgs &p, f32x4 *slab_m
   }
 }
 
+// The same tiling on the f16 pipe: each float32 product as three v_mfma_f32_32x32x16_f16 on two-piece operands (f16_split.h).
+// K of an MFMA = 16 batch rows, so a block is 16 rows: global -> registers two blocks ahead -> split (one power-of-two lift
+// per (member, operand), from the largest magnitude the producing kernel left in `amax / bmax`: the batch is the K dimension,
+// so a lift may not vary from row to row) -> LDS as two-piece [row][feature] images -> the hardware's transposed read
+// (ds_read_b64_tr_b16: four batch rows of one feature per read, cdna_hip_programming.md T10) delivers MFMA fragments with
+// the batch on the k index.  24 MFMAs of 32 cycles per block and wave against the 64 of 64 cycles the fp32 form needs for
+// the same 16 rows.  Row strides of the images are 16 dwords past a multiple of 64 (8 for the 512-wide A slab, which has to
+// fit two workgroups per CU): the four rows of a transposed read fall on different banks.
+template <int WM, int WN>
+__device__ __forceinline__ void wgrad_f16_body(const WgradArgs &p, char *smem, int bx, int by, int e) {
+  constexpr int TM = 128 * WM, TN = 64 * WN;
+  constexpr int SA = TM + (WM == 4 ? 16 : 32), SB = TN + 32;     // row strides, halves
+  constexpr int A_BYTES = 2 * 16 * SA * 2, B_BYTES = 2 * 16 * SB * 2, BUF = A_BYTES + B_BYTES;
+  constexpr int A4 = 16 * TM / 4, B4 = 16 * TN / 4;              // float4 per block
+  constexpr int A_PER = A4 / kThreads, B_PER = (B4 + kThreads - 1) / kThreads;
+  static_assert(A4 % kThreads == 0 && (kThreads % (TM / 4)) == 0 && (kThreads % (TN / 4)) == 0, "a thread keeps its columns");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int mt = bx / p.n_tiles, nt = bx - mt * p.n_tiles;
+  const int m0 = mt * TM, n0 = nt * TN;
+  const int start = by * p.rows_per_wg;
+  const int end = min(start + p.rows_per_wg, p.B);
+  const float *Abase = p.A + (size_t)e * p.B * p.lda + m0;
+  const float *Bbase = p.Bm + (size_t)e * p.B * p.ldb + n0;
+  // the member's largest operand magnitudes -> one power-of-two lift per operand
+  float la, lb;
+  {
+    float ma = 0.0f, mb = 0.0f;
+    for (int k = tid; k < p.max_tiles; k += kThreads) {
+      ma = fmaxf(ma, p.amax[((size_t)e * p.max_tiles + k) * kOpMax]);
+      mb = fmaxf(mb, p.bmax[((size_t)e * p.max_tiles + k) * kOpMax]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ma = fmaxf(ma, __shfl_xor(ma, o, 64)); mb = fmaxf(mb, __shfl_xor(mb, o, 64)); }
+    float *red = reinterpret_cast<float *>(smem);
+    if (lane == 0) { red[wave] = ma; red[4 + wave] = mb; }
+    __syncthreads();
+    la = pow2_lift(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    lb = pow2_lift(fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
+    __syncthreads();
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+  const bool sum_b = p.bias_mode == 1 && mt == 0, sum_a = p.bias_mode == 2 && nt == 0;
+  f32x4 asum = {0.0f, 0.0f, 0.0f, 0.0f}, bsum = {0.0f, 0.0f, 0.0f, 0.0f};   // this thread's columns, over the blocks' rows
+
+  // register staging: ONE set -- a block is requested one block (24 MFMAs per wave, interleaved with the CU's other
+  // workgroup) before it is split into LDS.  A second set (two blocks of lead, as the fp32 form has) does not fit beside
+  // the 128 accumulators, the fragments and the split's temporaries: 588 B of scratch per lane for the 256 x 128 tiles,
+  // 860 B for the 512 x 64 ones (TWO_SETS keeps the loop for a build that finds the registers).
+  constexpr bool TWO_SETS = false;
+  f32x4 ra0[A_PER], rb0[B_PER], ra1[TWO_SETS ? A_PER : 1], rb1[TWO_SETS ? B_PER : 1];
+  auto fetch = [&](int r0, f32x4 (&ra)[A_PER], f32x4 (&rb)[B_PER]) {
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+      const int q = tid + u * kThreads;
+      const int row = q / (TM / 4), c4 = q - row * (TM / 4);
+      ra[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (r0 + row < end) ra[u] = *reinterpret_cast<const f32x4 *>(Abase + (size_t)(r0 + row) * p.lda + 4 * c4);
+    }
+#pragma unroll
+    for (int u = 0; u < B_PER; ++u) {
+      const int q = tid + u * kThreads;
+      const int row = q / (TN / 4), c4 = q - row * (TN / 4);
+      rb[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (q < B4 && r0 + row < end && n0 + 4 * c4 < p.ldb)
+        rb[u] = *reinterpret_cast<const f32x4 *>(Bbase + (size_t)(r0 + row) * p.ldb + 4 * c4);
+    }
+  };
+  auto stash = [&](int buf, const f32x4 (&ra)[A_PER], const f32x4 (&rb)[B_PER]) {
+    _Float16 *Ai = reinterpret_cast<_Float16 *>(smem + buf * BUF), *Bi = reinterpret_cast<_Float16 *>(smem + buf * BUF + A_BYTES);
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+      const int q = tid + u * kThreads;
+      const int row = q / (TM / 4), c4 = q - row * (TM / 4);
+      unsigned q1[2], q2[2];
+      split2<false>(ra[u][0], ra[u][1], la, q1[0], q2[0]);
+      split2<false>(ra[u][2], ra[u][3], la, q1[1], q2[1]);
+      *reinterpret_cast<uint2 *>(Ai + row * SA + 4 * c4) = make_uint2(q1[0], q1[1]);
+      *reinterpret_cast<uint2 *>(Ai + (16 + row) * SA + 4 * c4) = make_uint2(q2[0], q2[1]);
+      if (sum_a) asum += ra[u];
+    }
+#pragma unroll
+    for (int u = 0; u < B_PER; ++u) {
+      const int q = tid + u * kThreads;
+      if (q < B4) {
+        const int row = q / (TN / 4), c4 = q - row * (TN / 4);
+        unsigned q1[2], q2[2];
+        split2<false>(rb[u][0], rb[u][1], lb, q1[0], q2[0]);
+        split2<false>(rb[u][2], rb[u][3], lb, q1[1], q2[1]);
+        *reinterpret_cast<uint2 *>(Bi + row * SB + 4 * c4) = make_uint2(q1[0], q1[1]);
+        *reinterpret_cast<uint2 *>(Bi + (16 + row) * SB + 4 * c4) = make_uint2(q2[0], q2[1]);
+        if (sum_b) bsum += rb[u];
+      }
+    }
+  };
+  // fragment of the block's 16 rows (k = 8 (lane >> 5) + j) of columns c0 + (lane & 31): two transposed reads per piece
+  typedef __fp16 h16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+  typedef __attribute__((address_space(3))) h16x4 *lds_h4;
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  auto frag = [&](const _Float16 *img, int stride, int c0, f16x8 &p1, f16x8 &p2) {
+    const int t = lane & 15, g = lane >> 4;
+    const _Float16 *a = img + (8 * (g >> 1) + (t >> 2)) * stride + c0 + 16 * (g & 1) + 4 * (t & 3);
+    const u32x2 l1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)a));
+    const u32x2 h1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(a + 4 * stride)));
+    const u32x2 l2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(a + 16 * stride)));
+    const u32x2 h2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(a + 20 * stride)));
+    const u32x4 q1 = {l1[0], l1[1], h1[0], h1[1]}, q2 = {l2[0], l2[1], h2[0], h2[1]};
+    p1 = __builtin_bit_cast(f16x8, q1);
+    p2 = __builtin_bit_cast(f16x8, q2);
+  };
+  auto compute = [&](int buf) {
+    const _Float16 *Ai = reinterpret_cast<const _Float16 *>(smem + buf * BUF), *Bi = reinterpret_cast<const _Float16 *>(smem + buf * BUF + A_BYTES);
+    f16x8 b1[2], b2[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) frag(Bi, SB, wn * 64 + 32 * ni, b1[ni], b2[ni]);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      f16x8 a1, a2;
+      frag(Ai, SA, wm * 128 + 32 * mi, a1, a2);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) mm3(acc[mi][ni], a1, a2, b1[ni], b2[ni]);
+      __builtin_amdgcn_sched_barrier(0);      // one A fragment pair live at a time (hoisted, the four of them spill)
+    }
+  };
+
+  if (start < end) {
+    if constexpr (TWO_SETS) {
+      fetch(start, ra0, rb0);
+      if (start + 16 < end) fetch(start + 16, ra1, rb1);
+      stash(0, ra0, rb0);
+      __syncthreads();
+      // even blocks live in buffer 0, odd blocks in buffer 1
+#pragma unroll 1
+      for (int r0 = start; r0 < end; r0 += 32) {
+        if (r0 + 32 < end) fetch(r0 + 32, ra0, rb0);
+        compute(0);
+        if (r0 + 16 < end) stash(1, ra1, rb1);
+        __syncthreads();
+        if (r0 + 16 >= end) break;
+        if (r0 + 48 < end) fetch(r0 + 48, ra1, rb1);
+        compute(1);
+        if (r0 + 32 < end) stash(0, ra0, rb0);
+        __syncthreads();
+      }
+    } else {
+      fetch(start, ra0, rb0);
+      stash(0, ra0, rb0);
+      __syncthreads();
+      int buf = 0;
+#pragma unroll 1
+      for (int r0 = start; r0 < end; r0 += 16, buf ^= 1) {
+        const bool more = r0 + 16 < end;
+        if (more) fetch(r0 + 16, ra0, rb0);
+        compute(buf);
+        if (more) stash(buf ^ 1, ra0, rb0);
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- bias gradients: the threads that staged the same columns (tid, tid + TM / 4, ...) add their partial sums in order
+  if (sum_a || sum_b) {
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);
+    float *dst = p.bias_out + (size_t)by * p.bias_part + (size_t)e * p.bias_member;
+    if (sum_a) {
+      constexpr int NP = kThreads / (TM / 4);
+      *reinterpret_cast<f32x4 *>(red + 4 * tid) = asum;          // [part][TM]: tid = part * (TM / 4) + c4
+      __syncthreads();
+      for (int c = tid; c < TM; c += kThreads) {
+        float v = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) v += red[q * TM + c];
+        if (m0 + c < p.bias_n) dst[m0 + c] = v;
+      }
+    } else {
+      constexpr int NP = kThreads / (TN / 4);
+      *reinterpret_cast<f32x4 *>(red + 4 * tid) = bsum;
+      __syncthreads();
+      for (int c = tid; c < TN; c += kThreads) {
+        float v = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) v += red[q * TN + c];
+        if (n0 + c < p.bias_n) dst[n0 + c] = v;
+      }
+    }
+  }
+
+  const float un = 1.0f / (la * lb);          // both powers of two
+  const int m0w = m0 + wm * 128, n0w = n0 + wn * 64;
+  float *out = p.out + (size_t)by * p.out_part + (size_t)e * p.out_member;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = n0w + 32 * ni + i;
+      if (!p.transposed) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0w + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (n < p.n_out) out[(size_t)m * p.ldc + n] = acc[mi][ni][r] * un;
+        }
+      } else if (n < p.n_out) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = m0w + 32 * mi + 8 * q + 4 * h;
+          *reinterpret_cast<f32x4 *>(out + (size_t)n * p.ldc + m) =
+              f32x4{acc[mi][ni][4 * q] * un, acc[mi][ni][4 * q + 1] * un, acc[mi][ni][4 * q + 2] * un, acc[mi][ni][4 * q + 3] * un};
+        }
+      }
+    }
+}
+
 // All three weight-gradient GEMMs of a 512-wide ensemble in one launch: the square layer's 256 x 128 tiles first, the
 // two narrow layers' 512 x 64 tiles behind them, so the small grids fill the CUs the big one frees instead of each
 // running alone on half of the chip.  Workgroup index -> (layer segment, tile, K split, member).
@@ -595,8 +850,11 @@ struct WgradAllArgs {
   int n_chunks0;           // (member, split) chunks of the first segment; its index space is padded to a multiple of 64
 };
 
+constexpr int kWgradF16Lds = 2 * (2 * 16 * (512 + 16) * 2 + 2 * 16 * (64 + 32) * 2);   // the (4 x 1) tiles' two buffers: 79 872 B
+
+template <bool F16>
 __global__ __launch_bounds__(kThreads, 2) void wgrad_all_kernel(const WgradAllArgs p) {
-  __shared__ f32x4 slab_mem[2 * (8 * 512 / 4 + 8 * 64 / 4)];
+  extern __shared__ f32x4 slab_mem[];     // fp32: 2 x (8 x 512 / 4 + 8 x 64 / 4) float4; f16: kWgradF16Lds bytes
   const int blk = blockIdx.x;
   const int seg = blk < p.first[1] ? 0 : (blk < p.first[2] ? 1 : 2);
   int q = blk - p.first[seg];
@@ -610,13 +868,15 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_all_kernel(const WgradAllAr
     const int bx = slot % T;
     const int c = (slot / T) * 8 + xcd;
     if (c >= p.n_chunks0) return;
-    wgrad_lds_body<2, 2>(p.g[0], slab_mem, bx, c % p.ks[0], c / p.ks[0]);
+    if constexpr (F16) wgrad_f16_body<2, 2>(p.g[0], reinterpret_cast<char *>(slab_mem), bx, c % p.ks[0], c / p.ks[0]);
+    else wgrad_lds_body<2, 2>(p.g[0], slab_mem, bx, c % p.ks[0], c / p.ks[0]);
     return;
   }
   const int bx = q % p.tiles[seg];
   q /= p.tiles[seg];
   const int by = q % p.ks[seg], e = q / p.ks[seg];
-  wgrad_lds_body<4, 1>(p.g[seg], slab_mem, bx, by, e);
+  if constexpr (F16) wgrad_f16_body<4, 1>(p.g[seg], reinterpret_cast<char *>(slab_mem), bx, by, e);
+  else wgrad_lds_body<4, 1>(p.g[seg], slab_mem, bx, by, e);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1009,13 +1269,24 @@ struct cmbpo_trainer {
   double *sums;
   double *loss_part;             // [E * ceil(max_batch / 32)][3] per-tile loss statistics of the training forward
   size_t wsize[3], bsize[3];
+  float *opmax;                  // [E][ceil(max_batch / 32)][kOpMax] per-tile largest |x|, |h1|, |h2|, |d1|, |d2|, |d3| of the step
 };
 
 namespace {
 
+// 0: the training GEMMs as fp32 MFMAs (rounds 1-2); 1: three f16 MFMAs per product on split operands (512-wide ensembles)
+int g_train_f16 = -1;
+bool train_f16() {
+  if (g_train_f16 < 0) {
+    const char *e = getenv("CMBPO_TRAIN_F16");
+    g_train_f16 = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_train_f16 != 0;
+}
+
 int wgrad_rows_per_wg(int batch, int ks) {
   int rows = cmbpo_ceil_div(batch, ks);
-  return (rows + 7) / 8 * 8;   // 4 waves x an even row count
+  return (rows + 15) / 16 * 16;   // whole 16-row blocks (the f16 form's K per MFMA; the fp32 form needs a multiple of 8)
 }
 
 void fill_wgrad_args(cmbpo_trainer *t, int layer, int batch, WgradArgs &a, int &n_cols);
@@ -1059,7 +1330,17 @@ int launch_wgrad_all(cmbpo_trainer *t, int batch, hipStream_t s) {
     }
   }
   all.first[3] = blocks;
-  hipLaunchKernelGGL(wgrad_all_kernel, dim3(blocks), dim3(kThreads), 0, s, all);
+  if (train_f16()) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_all_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kWgradF16Lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_all_kernel<true>, dim3(blocks), dim3(kThreads), kWgradF16Lds, s, all);
+  } else {
+    hipLaunchKernelGGL(wgrad_all_kernel<false>, dim3(blocks), dim3(kThreads), 2 * (8 * 512 / 4 + 8 * 64 / 4) * sizeof(f32x4), s, all);
+  }
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }
@@ -1070,14 +1351,17 @@ void fill_wgrad_args(cmbpo_trainer *t, int layer, int batch, WgradArgs &a, int &
     a.A = t->d1; a.lda = H; a.Bm = t->x; a.ldb = t->IP; n_cols = t->IP;
     a.ldc = H; a.transposed = 1; a.n_out = t->I;
     a.bias_mode = 2; a.bias_n = H;          // db0 = column sums of d1
+    a.amax = t->opmax + 3; a.bmax = t->opmax + 0;
   } else if (layer == 1) {  // dW1 = h1^T d2
     a.A = t->h1; a.lda = H; a.Bm = t->d2; a.ldb = H; n_cols = H;
     a.ldc = H; a.transposed = 0; a.n_out = H;
     a.bias_mode = 1; a.bias_n = H;          // db1 = column sums of d2
+    a.amax = t->opmax + 1; a.bmax = t->opmax + 4;
   } else {                  // dW2 = h2^T d3
     a.A = t->h2; a.lda = H; a.Bm = t->d3; a.ldb = t->OPk; n_cols = t->OPk;
     a.ldc = t->O; a.transposed = 0; a.n_out = t->O;
     a.bias_mode = 1; a.bias_n = t->O;       // db2 = column sums of d3
+    a.amax = t->opmax + 2; a.bmax = t->opmax + 5;
   }
   a.bias_out = t->dB[layer];
   a.bias_member = t->bsize[layer] / t->E;
@@ -1087,6 +1371,7 @@ void fill_wgrad_args(cmbpo_trainer *t, int layer, int batch, WgradArgs &a, int &
   a.out_part = t->wsize[layer];
   a.B = batch;
   a.rows_per_wg = wgrad_rows_per_wg(batch, t->ks[layer]);
+  a.max_tiles = cmbpo_ceil_div(batch, 32);
 }
 
 template <int HID>
@@ -1205,6 +1490,7 @@ int run_forward(cmbpo_trainer *t, const float *d_inputs, const int32_t *d_idx, i
   a.out0 = t->o;
   if (exports) { a.tr_x = t->x; a.tr_h1 = t->h1; a.tr_g1 = t->g1; a.tr_h2 = t->h2; a.tr_g2 = t->g2; }
   if (d_targets) { a.tr_targets = d_targets; a.tr_tdim = t->D; a.tr_loss_part = t->loss_part; }
+  if (exports) a.tr_opmax = t->opmax;          // (indexed by item = member * tiles + tile, like the loss statistics)
   return cmbpo_internal_launch_mlp(t->m, a, s, CMBPO_HEAD_TRAIN);
 }
 
@@ -1281,6 +1567,7 @@ extern "C" int cmbpo_trainer_create(cmbpo_trainer_t **out, cmbpo_mlp_t *m, int m
                od1 = take(rows * H);
   const size_t osums = take(2 * 3 * (size_t)E);   // doubles
   const size_t olp = take(2 * 3 * (size_t)E * cmbpo_ceil_div(max_batch, 32));   // doubles
+  const size_t oom = take((size_t)E * cmbpo_ceil_div(max_batch, 32) * kOpMax);
   hipError_t err = hipMalloc(reinterpret_cast<void **>(&t->pool), off * sizeof(float));
   if (err != hipSuccess) {
     cmbpo_set_error("cmbpo_trainer_create: hipMalloc(%zu) failed: %s", off * sizeof(float), hipGetErrorString(err));
@@ -1305,6 +1592,7 @@ extern "C" int cmbpo_trainer_create(cmbpo_trainer_t **out, cmbpo_mlp_t *m, int m
   t->o = P + oo; t->d3 = P + od3; t->d2 = P + od2; t->d1 = P + od1;
   t->sums = reinterpret_cast<double *>(P + osums);
   t->loss_part = reinterpret_cast<double *>(P + olp);
+  t->opmax = P + oom;
   *out = t;
   return CMBPO_OK;
 }
@@ -1465,6 +1753,7 @@ extern "C" int cmbpo_trainer_step(cmbpo_trainer_t *t, const float *d_inputs, int
     b.out_mu = m->has_out_scaler ? m->d_blob + m->off_out_mu : nullptr;
     b.out_sig = m->has_out_scaler ? m->d_blob + m->off_out_var : nullptr;
     b.loss_part = t->loss_part; b.d3_out = t->d3;
+    b.opmax = t->opmax;
   }
   const size_t lds = ((size_t)H / 4 * 32 + (size_t)t->OPk / 4 * 32) * sizeof(f32x4);
   const int tiles = cmbpo_ceil_div(batch, 32);

@@ -390,11 +390,14 @@ __global__ __launch_bounds__(256) void store_stats_kernel(const cmbpo_rollout_t 
 // in a fixed tree.  (Single-rank path: the cross-shard budget exchange keeps the separate kernels.)
 constexpr int kBookMax = 4096;
 
-__global__ __launch_bounds__(kScanThreads) void book_pre_kernel(const cmbpo_rollout_t r) {
+// spec (cmbpo_rollout_run's look-ahead): the step was enqueued before the host saw the previous step's counters -- it is void
+// when that step raised the halt word (book_post_kernel)
+__global__ __launch_bounds__(kScanThreads) void book_pre_kernel(const cmbpo_rollout_t r, int spec) {
   __shared__ int sm_i[17];
   __shared__ double sm_d[16];
   __shared__ int s_unc;
   const int tid = threadIdx.x;
+  if (spec && r.iscal[CMBPO_I_HALT]) return;
   const int n = r.iscal[CMBPO_I_N_ALIVE];
   // (1) uncertainty flags + this step's counters (decide_flags_kernel / head of decide_budget_kernel)
   {
@@ -501,8 +504,9 @@ __global__ __launch_bounds__(kScanThreads) void book_pre_kernel(const cmbpo_roll
 }
 
 // the vector half of the store for book_pre_kernel's decisions: 64-row tiles on as many workgroups
-__global__ __launch_bounds__(256) void store_vec_kernel(const cmbpo_rollout_t r) {
+__global__ __launch_bounds__(256) void store_vec_kernel(const cmbpo_rollout_t r, int spec) {
   __shared__ int s_slot[kStoreRows];
+  if (spec && r.iscal[CMBPO_I_HALT]) return;
   const int n = r.iscal[CMBPO_I_N_ALIVE];
   const int tid = threadIdx.x;
   const int row0 = blockIdx.x * kStoreRows;
@@ -541,10 +545,15 @@ __global__ __launch_bounds__(256) void store_vec_kernel(const cmbpo_rollout_t r)
 // host_out (optional): a host-mapped, coherent block of 128 dwords -- the step's counters (iscal | dscal, 96 dwords) are
 // written straight into it, then a system-scope fence, then `seq` at dword 96: the host polls that word instead of paying a
 // copy + a stream synchronisation per step (cmbpo_rollout_run)
-__global__ __launch_bounds__(kScanThreads) void book_post_kernel(const cmbpo_rollout_t r, uint32_t *host_out, uint32_t seq) {
+// spec: the step may be void (see book_pre_kernel); a step that is not decides whether the NEXT one is -- the caller's stop tests
+// (at most min_alive rows left, total_samples >= stop_total unless NaN; algorithms/cmbpo.py:356-359) are taken here, the halt
+// word travels in the mirrored block and iscal[CMBPO_I_N_EFF] (the row count the next step's forward kernels read) drops to 0.
+__global__ __launch_bounds__(kScanThreads) void book_post_kernel(const cmbpo_rollout_t r, uint32_t *host_out, uint32_t seq, int spec,
+                                                                 int min_alive, double stop_total) {
   __shared__ int sm_i[17];
   __shared__ double sm_d[16];
   const int tid = threadIdx.x;
+  if (spec && r.iscal[CMBPO_I_HALT]) return;
   const int n = r.iscal[CMBPO_I_N_ALIVE];
   const bool horizon = (r.ptr + 1 >= r.max_path_length - 1);     // path_length after the store, model_sampler.py:352
   int nfin = 0;
@@ -578,6 +587,11 @@ __global__ __launch_bounds__(kScanThreads) void book_post_kernel(const cmbpo_rol
   if (tid == 0) {
     r.iscal[CMBPO_I_N_ALIVE_OUT] = carry;
     r.iscal[CMBPO_I_N_ALIVE] = carry;           // the caller swaps alive_idx <-> alive_idx_out
+    if (spec) {
+      const int halt = (carry <= 0 || carry <= min_alive || (stop_total == stop_total && r.dscal[CMBPO_D_TOTAL_SAMPLES] >= stop_total)) ? 1 : 0;
+      r.iscal[CMBPO_I_HALT] = halt;
+      r.iscal[CMBPO_I_N_EFF] = halt ? 0 : carry;
+    }
     if (host_out != nullptr) {
       // (this thread wrote the last counters itself; the accumulators were left by book_pre_kernel, an earlier launch)
       const uint4 *src = reinterpret_cast<const uint4 *>(r.iscal);      // iscal[32] | dscal[32]: one 384-byte block
@@ -1146,8 +1160,30 @@ extern "C" int cmbpo_rollout_book_pre(const cmbpo_rollout_t *r, int n_alive, voi
                     r->logp_buf && r->adv_buf && r->ret_buf && r->cadv_buf && r->cret_buf,
                 "cmbpo_rollout_book_pre: NULL buffer");
   if (n_alive == 0) return CMBPO_OK;
-  hipLaunchKernelGGL(book_pre_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r);
-  hipLaunchKernelGGL(store_vec_kernel, dim3(cmbpo_ceil_div(n_alive, kStoreRows)), dim3(256), 0, (hipStream_t)stream, *r);
+  hipLaunchKernelGGL(book_pre_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r, 0);
+  hipLaunchKernelGGL(store_vec_kernel, dim3(cmbpo_ceil_div(n_alive, kStoreRows)), dim3(256), 0, (hipStream_t)stream, *r, 0);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+// the same for a step enqueued ahead of the previous step's counters (cmbpo_rollout_run): n_alive is an upper bound
+int cmbpo_internal_book_pre_spec(const cmbpo_rollout_t *r, int n_alive, void *stream) {
+  if (int rc = check_rollout(r, "cmbpo_rollout_book_pre")) return rc;
+  CMBPO_REQUIRE(n_alive >= 1 && n_alive <= kBookMax && !r->use_host_budget && r->ptr < r->T, "book_pre (look-ahead): bad state");
+  hipLaunchKernelGGL(book_pre_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r, 1);
+  hipLaunchKernelGGL(store_vec_kernel, dim3(cmbpo_ceil_div(n_alive, kStoreRows)), dim3(256), 0, (hipStream_t)stream, *r, 1);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+// look-ahead bookkeeping of cmbpo_rollout_run: begin = no halt, the forward kernels' row count = the alive count; end = no halt
+__global__ void spec_words_kernel(const cmbpo_rollout_t r, int begin) {
+  r.iscal[CMBPO_I_HALT] = 0;
+  r.iscal[CMBPO_I_N_EFF] = begin ? r.iscal[CMBPO_I_N_ALIVE] : 0;
+}
+int cmbpo_internal_spec_words(const cmbpo_rollout_t *r, int begin, void *stream) {
+  CMBPO_REQUIRE(r && r->iscal, "look-ahead words: NULL argument");
+  hipLaunchKernelGGL(spec_words_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, *r, begin);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }
@@ -1158,7 +1194,7 @@ extern "C" int cmbpo_rollout_book_post(const cmbpo_rollout_t *r, int n_alive, vo
   CMBPO_REQUIRE(r->v_n && r->vc_n && r->term_t && r->rew_buf && r->val_buf && r->cost_buf && r->cval_buf && r->adv_buf &&
                     r->ret_buf && r->cadv_buf && r->cret_buf,
                 "cmbpo_rollout_book_post: NULL array");
-  hipLaunchKernelGGL(book_post_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r, (uint32_t *)nullptr, 0u);
+  hipLaunchKernelGGL(book_post_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r, (uint32_t *)nullptr, 0u, 0, 0, 0.0);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }
@@ -1186,7 +1222,9 @@ int cmbpo_internal_scalars_mirror(const cmbpo_rollout_t *r, uint32_t *d_host_out
 }
 
 // the same with the counters mirrored into host-mapped memory (d_host_out: device address of 128 dwords) and `seq` behind them
-int cmbpo_internal_book_post_mirror(const cmbpo_rollout_t *r, int n_alive, uint32_t *d_host_out, uint32_t seq, void *stream) {
+// spec: see book_post_kernel
+int cmbpo_internal_book_post_mirror(const cmbpo_rollout_t *r, int n_alive, uint32_t *d_host_out, uint32_t seq, int spec, int min_alive,
+                                    double stop_total, void *stream) {
   if (int rc = check_rollout(r, "cmbpo_rollout_book_post")) return rc;
   CMBPO_REQUIRE(n_alive >= 0 && n_alive <= kBookMax, "cmbpo_rollout_book_post: %d alive rows, at most %d", n_alive, kBookMax);
   CMBPO_REQUIRE(r->v_n && r->vc_n && r->term_t && r->rew_buf && r->val_buf && r->cost_buf && r->cval_buf && r->adv_buf &&
@@ -1194,7 +1232,8 @@ int cmbpo_internal_book_post_mirror(const cmbpo_rollout_t *r, int n_alive, uint3
                 "cmbpo_rollout_book_post: NULL array");
   CMBPO_REQUIRE(reinterpret_cast<const char *>(r->dscal) == reinterpret_cast<const char *>(r->iscal) + 128,
                 "cmbpo_rollout_book_post: iscal[32] and dscal[32] must be one 384-byte block");
-  hipLaunchKernelGGL(book_post_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r, d_host_out, seq);
+  hipLaunchKernelGGL(book_post_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r, d_host_out, seq, spec, min_alive,
+                     stop_total);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }

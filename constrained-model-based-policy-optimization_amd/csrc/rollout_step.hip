@@ -13,8 +13,20 @@
 #include <atomic>
 #include <mutex>
 
-int cmbpo_internal_book_post_mirror(const cmbpo_rollout_t *r, int n_alive, uint32_t *d_host_out, uint32_t seq, void *stream);
+int cmbpo_internal_book_post_mirror(const cmbpo_rollout_t *r, int n_alive, uint32_t *d_host_out, uint32_t seq, int spec, int min_alive,
+                                    double stop_total, void *stream);
 int cmbpo_internal_scalars_mirror(const cmbpo_rollout_t *r, uint32_t *d_host_out, uint32_t seq, void *stream);
+int cmbpo_internal_book_pre_spec(const cmbpo_rollout_t *r, int n_alive, void *stream);
+int cmbpo_internal_spec_words(const cmbpo_rollout_t *r, int begin, void *stream);
+
+// A step enqueued AHEAD of the previous step's counters (cmbpo_rollout_run, small batches): n_alive is then an upper bound (the
+// alive count only falls), every kernel reads the row count on the device, and the step is void if the previous one met a stop
+// test (min_alive / stop_total, decided by its last kernel: book_post_kernel).
+struct Ahead {
+  bool on = false;
+  int min_alive = 0;
+  double stop_total = 0.0;
+};
 
 // policy_ready: this step's actions are already in act_t / logp_t / mu_t / ls_t (the previous step's critic launch carried
 // the actor along).  d_eps_next != NULL: let this step's critic launch carry the actor for the NEXT step (its noise), if the
@@ -22,25 +34,31 @@ int cmbpo_internal_scalars_mirror(const cmbpo_rollout_t *r, uint32_t *d_host_out
 static int step_impl(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy, cmbpo_mlp_t *model, cmbpo_mlp_t *v,
                      cmbpo_mlp_t *vc, int task, int ensemble, const float *d_eps, const int32_t *d_elite, float *d_mean,
                      float *d_var, bool policy_ready, const float *d_eps_next, bool *next_ready, uint32_t *d_mirror, uint32_t seq,
-                     void *stream) {
+                     const Ahead &ahead, void *stream) {
   CMBPO_REQUIRE(r && policy && model && v && vc && d_eps && d_elite && d_mean && d_var, "cmbpo_rollout_step: NULL argument");
   CMBPO_REQUIRE(n_alive >= 1 && n_alive <= r->B, "cmbpo_rollout_step: n_alive %d not in [1, B=%d]", n_alive, r->B);
   // the per-step arrays are inputs of the bookkeeping kernels (const in the struct) and outputs of the forward passes
   auto w = [](const float *p) { return const_cast<float *>(p); };
   int rc;
   *next_ready = false;
+  const int32_t *d_n = ahead.on ? r->iscal + CMBPO_I_N_EFF : nullptr;     // the forward kernels' row count (device) / n_alive (host)
+  if (ahead.on)
+    CMBPO_REQUIRE(n_alive <= cmbpo_rollout_book_pre_max_rows() && !r->use_host_budget && d_mirror && cmbpo_critic_pair_supported(v, vc),
+                  "cmbpo_rollout_run: look-ahead needs the small-batch step");
   if (!policy_ready &&
-      (rc = cmbpo_policy_forward(policy, r->cur_obs, r->obs_dim, d_eps, r->alive_idx, nullptr, n_alive, w(r->act_t), w(r->logp_t),
+      (rc = cmbpo_policy_forward(policy, r->cur_obs, r->obs_dim, d_eps, r->alive_idx, d_n, n_alive, w(r->act_t), w(r->logp_t),
                                  w(r->mu_t), w(r->ls_t), stream)))
     return rc;
-  if ((rc = cmbpo_ens_forward(model, r->cur_obs, r->obs_dim, r->act_t, r->act_dim, r->alive_idx, nullptr, n_alive, r->B,
+  if ((rc = cmbpo_ens_forward(model, r->cur_obs, r->obs_dim, r->act_t, r->act_dim, r->alive_idx, d_n, n_alive, r->B,
                               d_mean, d_var, stream)))
     return rc;
   if ((rc = cmbpo_fakeenv_post(task, ensemble, r->obs_dim, r->act_dim, d_mean, d_var, r->B, r->cur_obs, r->act_t, d_elite,
-                               r->alive_idx, nullptr, n_alive, w(r->next_obs), w(r->rew_t), const_cast<uint8_t *>(r->term_t), w(r->cost_t),
+                               r->alive_idx, d_n, n_alive, w(r->next_obs), w(r->rew_t), const_cast<uint8_t *>(r->term_t), w(r->cost_t),
                                w(r->dkl_t), w(r->epv_t), nullptr, stream)))
     return rc;
-  if (n_alive <= cmbpo_rollout_book_pre_max_rows() && !r->use_host_budget) {
+  if (ahead.on) {
+    if ((rc = cmbpo_internal_book_pre_spec(r, n_alive, stream))) return rc;
+  } else if (n_alive <= cmbpo_rollout_book_pre_max_rows() && !r->use_host_budget) {
     if ((rc = cmbpo_rollout_book_pre(r, n_alive, stream))) return rc;     // decide + finish(PRE) + store in one launch
   } else {
     if ((rc = cmbpo_rollout_decide(r, stream))) return rc;
@@ -53,7 +71,7 @@ static int step_impl(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy,
     static const int ride_max = getenv("CMBPO_RIDE_MAX_ROWS") ? atoi(getenv("CMBPO_RIDE_MAX_ROWS")) : (1 << 30);
     const bool ride = d_eps_next != nullptr && n_alive <= ride_max && n_alive < cmbpo_internal_critic_big_min() &&
                       cmbpo_internal_critic_pair_can_ride(v, vc, policy);     // (large batches: the member-after-member kernel)
-    if ((rc = cmbpo_internal_critic_pair_ride(v, vc, r->next_obs, r->obs_dim, r->alive_idx, nullptr, n_alive, w(r->v_n), w(r->vc_n),
+    if ((rc = cmbpo_internal_critic_pair_ride(v, vc, r->next_obs, r->obs_dim, r->alive_idx, d_n, n_alive, w(r->v_n), w(r->vc_n),
                                               ride ? policy : nullptr, d_eps_next, w(r->act_t), w(r->logp_t), w(r->mu_t), w(r->ls_t),
                                               stream)))
       return rc;
@@ -64,7 +82,9 @@ static int step_impl(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy,
   }
   if (n_alive <= cmbpo_rollout_book_pre_max_rows() && !r->use_host_budget) {
     // finish(POST) + compaction in one launch (with the step's counters mirrored to the host, if asked)
-    if ((rc = d_mirror ? cmbpo_internal_book_post_mirror(r, n_alive, d_mirror, seq, stream) : cmbpo_rollout_book_post(r, n_alive, stream)))
+    if ((rc = d_mirror ? cmbpo_internal_book_post_mirror(r, n_alive, d_mirror, seq, ahead.on ? 1 : 0, ahead.min_alive, ahead.stop_total,
+                                                         stream)
+                       : cmbpo_rollout_book_post(r, n_alive, stream)))
       return rc;
     return 1;                                                              // the alive list has been rebuilt: swap it
   }
@@ -76,7 +96,7 @@ extern "C" int cmbpo_rollout_step(const cmbpo_rollout_t *r, int n_alive, cmbpo_m
                                   const int32_t *d_elite, float *d_mean, float *d_var, void *stream) {
   bool unused = false;
   return step_impl(r, n_alive, policy, model, v, vc, task, ensemble, d_eps, d_elite, d_mean, d_var, false, nullptr, &unused, nullptr, 0u,
-                   stream);
+                   Ahead{}, stream);
 }
 
 // Several steps in one call: what ModelSampler.sample()'s caller does between two steps (read the step's counters, swap the
@@ -161,15 +181,71 @@ extern "C" int cmbpo_rollout_run(cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *p
   CMBPO_REQUIRE(!r->use_host_budget, "cmbpo_rollout_run: the cross-shard budget exchange needs the per-step path");
   int done = 0, swaps = 0;
   bool ready = false;     // the actor for the step about to run was evaluated by the previous step's critic launch
+  auto advance = [&](bool swap_lists) {     // what the per-step caller does between two steps
+    if (swap_lists) {
+      int32_t *t = r->alive_idx; r->alive_idx = r->alive_idx_out; r->alive_idx_out = t;
+      ++swaps;
+    }
+    { const float *t = r->cur_obs; r->cur_obs = r->next_obs; r->next_obs = t; }
+    { const float *t = r->v_t; r->v_t = r->v_n; r->v_n = t; }
+    { const float *t = r->vc_t; r->vc_t = r->vc_n; r->vc_n = t; }
+    r->ptr += 1;
+  };
+  static const bool ahead_env = !(getenv("CMBPO_STEP_AHEAD") && getenv("CMBPO_STEP_AHEAD")[0] == '0');
   while (done < max_steps && n_alive > 0 && r->ptr < r->T) {
+    Mirror &mir = mirror();
+    if (ahead_env && mir.d && n_alive <= cmbpo_rollout_book_pre_max_rows() && cmbpo_critic_pair_supported(v, vc)) {
+      // ---- small batches, to the end of the call: step k + 1 is enqueued BEFORE the host waits for step k's counters, so the
+      // GPU never idles across the host's round trip (13 of 93 us per step at 1000 branches).  Nothing the host does between
+      // two steps needs the counters -- the lists are swapped after every small-batch step, the column advances by one -- except
+      // the stop tests: book_post_kernel takes them on the device and raises the halt word that voids the step behind it; the
+      // host reads the same word from the mirrored block, so both sides always agree on the last step.
+      Ahead ah;
+      ah.on = true; ah.min_alive = min_alive; ah.stop_total = stop_total;
+      if (int rc = cmbpo_internal_spec_words(r, 1, stream)) return rc;
+      struct Pend { int slot; uint32_t seq; };
+      auto enqueue = [&](int k, Pend &p) -> int {       // step k of this call, from the struct as step k - 1 left it
+        const float *eps_next = k + 1 < max_steps ? d_eps + (size_t)(k + 1) * eps_stride : nullptr;
+        bool next_ready = false;
+        p.slot = k % kMirrorSlots;
+        p.seq = next_seq();
+        const int rc = step_impl(r, n_alive, policy, model, v, vc, task, ensemble, d_eps + (size_t)k * eps_stride,
+                                 d_elite + (size_t)k * elite_stride, d_mean, d_var, ready, eps_next, &next_ready,
+                                 mir.d + (size_t)p.slot * kMirrorDwords, p.seq, ah, stream);
+        ready = next_ready;
+        if (rc == 0) cmbpo_set_error("cmbpo_rollout_run: look-ahead step took the large-batch path");
+        return rc == 1 ? CMBPO_OK : (rc == 0 ? CMBPO_EINVAL : rc);
+      };
+      Pend cur{}, nxt{};
+      if (int rc = enqueue(done, cur)) return rc;
+      bool halted = false;
+      for (;;) {
+        advance(true);
+        const bool more = done + 1 < max_steps && r->ptr < r->T;     // (the host's own limits; n_alive stays an upper bound)
+        if (more)
+          if (int rc = enqueue(done + 1, nxt)) return rc;
+        const uint32_t *h_slot = mir.h + (size_t)cur.slot * kMirrorDwords;
+        if (int rc2 = wait_mirror(h_slot, cur.seq, (hipStream_t)stream)) return rc2;
+        char *h = static_cast<char *>(h_scalars) + (size_t)done * 384;
+        memcpy(h, h_slot, 384);
+        const int32_t *isc = reinterpret_cast<const int32_t *>(h);
+        n_alive = isc[CMBPO_I_N_ALIVE];
+        halted = isc[CMBPO_I_HALT] != 0;
+        ++done;
+        if (halted || !more) break;
+        cur = nxt;
+      }
+      if (halted)       // (the void step behind the last one has run by then: stream order)
+        if (int rc = cmbpo_internal_spec_words(r, 0, stream)) return rc;
+      break;
+    }
     const float *eps_next = done + 1 < max_steps ? d_eps + (size_t)(done + 1) * eps_stride : nullptr;
     bool next_ready = false;
-    Mirror &mir = mirror();
     const int slot = done % kMirrorSlots;
     const uint32_t seq = next_seq();
     uint32_t *d_slot = mir.d ? mir.d + (size_t)slot * kMirrorDwords : nullptr;
     int rc = step_impl(r, n_alive, policy, model, v, vc, task, ensemble, d_eps + (size_t)done * eps_stride,
-                       d_elite + (size_t)done * elite_stride, d_mean, d_var, ready, eps_next, &next_ready, d_slot, seq, stream);
+                       d_elite + (size_t)done * elite_stride, d_mean, d_var, ready, eps_next, &next_ready, d_slot, seq, Ahead{}, stream);
     ready = next_ready;
     if (rc != 0 && rc != 1) return rc;
     char *h = static_cast<char *>(h_scalars) + (size_t)done * 384;
@@ -194,15 +270,8 @@ extern "C" int cmbpo_rollout_run(cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *p
       if (int rc2 = cmbpo_rollout_compact(r, stream)) return rc2;           // the alive list only changes when a branch finished
       swap_lists = true;
     }
-    if (swap_lists) {
-      int32_t *t = r->alive_idx; r->alive_idx = r->alive_idx_out; r->alive_idx_out = t;
-      ++swaps;
-    }
     n_alive -= fin;
-    { const float *t = r->cur_obs; r->cur_obs = r->next_obs; r->next_obs = t; }
-    { const float *t = r->v_t; r->v_t = r->v_n; r->v_n = t; }
-    { const float *t = r->vc_t; r->vc_t = r->vc_n; r->vc_n = t; }
-    r->ptr += 1;
+    advance(swap_lists);
     ++done;
     if (n_alive <= min_alive) break;
     if (stop_total == stop_total && dsc[CMBPO_D_TOTAL_SAMPLES] >= stop_total) break;     // NaN: no such test

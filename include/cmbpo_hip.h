@@ -227,6 +227,9 @@ typedef struct cmbpo_rollout {
 #define CMBPO_I_N_ALIVE_OUT 4 /* length of alive_idx_out after compact          */
 #define CMBPO_I_SIZE 5      /* populated entries in the buffer (pool.size)      */
 #define CMBPO_I_N_FIN_POST 6 /* rows finished after the store (horizon / terminal) */
+/* (8 .. 11: the row other shards gather -- {n_alive, n_unc, total_samples, 0}) */
+#define CMBPO_I_HALT 12     /* cmbpo_rollout_run's look-ahead: the step just taken met a stop test, the step enqueued behind it is void */
+#define CMBPO_I_N_EFF 13    /* ... and the row count that step's forward kernels read (0 once halted)   */
 /* dscal slots (sampler accumulators, model_sampler.py:314-333) */
 #define CMBPO_D_TOTAL_SAMPLES 0
 #define CMBPO_D_TOTAL_COST 1

@@ -179,6 +179,9 @@ __device__ __forceinline__ void static_for(F &&f) {
 #define H3_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
+#ifndef H3_EPI_FUSE
+#define H3_EPI_FUSE 1       // diagnostic: 0 = round 2's epilogue (separate product z sigma(z), the lift in the split's FMAs)
+#endif
 #ifndef H3_TAIL_RING
 #define H3_TAIL_RING 0      // diagnostic: 1 = W2 fragments through the two-slab ring for every shape (round 2's tail)
 #endif
@@ -370,7 +373,8 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
 
     // ---- layers 0 + 1, fused over the 8 chunks of h1 -------------------------------------------------------------------
     const int l0_tn = wave & (NTC - 1), l0_bt = wave / NTC;     // this wave's (n-tile, row-tile) pair of every chunk
-    const float inv0_l = r_inv0[32 * l0_bt + r] * kLog2e, t1_l = r_t1[32 * l0_bt + r] * kLn2;
+    const float inv0_l = r_inv0[32 * l0_bt + r] * kLog2e;
+    const float t1_l = H3_EPI_FUSE ? 1.0f / (r_t1[32 * l0_bt + r] * kLn2) : r_t1[32 * l0_bt + r] * kLn2;     // (FUSE: the epilogue takes 1 / lift)
     const _Float16 *xb0 = ximg + (size_t)(32 * l0_bt + r) * XSTR + 8 * hh;
     // layer-0 operands of one 16-deep slab: W0 fragments of the chunk (LDS copy) and this wave's rows of the x image
     struct L0Ops { f16x8 a1, a2, b1, b2; };
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
       for (int q = 0; q < 4; ++q) {
         Epi4 es;
         const f32x4 bv = l0_bias(0, q);
-        epi_all<false, true>(es, d, q, inv0_l, bv, t1_l);
+        epi_all<false, true, H3_EPI_FUSE>(es, d, q, inv0_l, bv, t1_l);
         l0_store(es, 0, q);
       }
     }
@@ -503,16 +507,16 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
           if (slot >= 4) {
 #endif
             const int q = slot - 4;
-            if (i == 0) epi_stage<0, true, true>(es, d, q, inv0_l, bv, t1_l);
-            if (i == 1) epi_stage<1, true, true>(es, d, q, inv0_l, bv, t1_l);
-            if (i == 2) epi_stage<2, true, true>(es, d, q, inv0_l, bv, t1_l);
-            if (i == 3) epi_stage<3, true, true>(es, d, q, inv0_l, bv, t1_l);
-            if (i == 4) epi_stage<4, true, true>(es, d, q, inv0_l, bv, t1_l);
-            if (i == 5) epi_stage<5, true, true>(es, d, q, inv0_l, bv, t1_l);
-            if (i == 6) epi_stage<6, true, true>(es, d, q, inv0_l, bv, t1_l);
-            if (i == 7) epi_stage<7, true, true>(es, d, q, inv0_l, bv, t1_l);
-            if (i == 8) epi_stage<8, true, true>(es, d, q, inv0_l, bv, t1_l);
-            if (i == 9) epi_stage<9, true, true>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 0) epi_stage<0, true, true, H3_EPI_FUSE>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 1) epi_stage<1, true, true, H3_EPI_FUSE>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 2) epi_stage<2, true, true, H3_EPI_FUSE>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 3) epi_stage<3, true, true, H3_EPI_FUSE>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 4) epi_stage<4, true, true, H3_EPI_FUSE>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 5) epi_stage<5, true, true, H3_EPI_FUSE>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 6) epi_stage<6, true, true, H3_EPI_FUSE>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 7) epi_stage<7, true, true, H3_EPI_FUSE>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 8) epi_stage<8, true, true, H3_EPI_FUSE>(es, d, q, inv0_l, bv, t1_l);
+            if (i == 9) epi_stage<9, true, true, H3_EPI_FUSE>(es, d, q, inv0_l, bv, t1_l);
             if (i == 10) l0_store(es, c + 1, q);
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -612,7 +616,8 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
       u32x4 bfu[2][4][2];        // [row tile & 1][slab of this wave's K slice][piece]
       auto stA = [&](auto RTI) {
         constexpr int rt = decltype(RTI)::value;
-        const float inv1_l = r_inv1[32 * rt + r] * kLog2e, t2_l = r_t2[32 * rt + r] * kLn2;
+        const float inv1_l = r_inv1[32 * rt + r] * kLog2e;
+        const float t2_l = H3_EPI_FUSE ? 1.0f / (r_t2[32 * rt + r] * kLn2) : r_t2[32 * rt + r] * kLn2;
         static_for<0, 8>([&](auto QD) {
           constexpr int quad = decltype(QD)::value, S = quad >> 1, jq = quad & 1, q = 2 * (S & 1) + jq;
           const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias1 + 64 * wave + 32 * (S >> 1) + 8 * q + 4 * hh);
@@ -621,7 +626,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
           es.q1[0] = __float_as_uint(acc[S >> 1][rt][4 * q] + bv[0]) & 0x3fff3fffu; es.q1[1] = __float_as_uint(acc[S >> 1][rt][4 * q + 1] + inv1_l) & 0x3fff3fffu;
           es.q2[0] = __float_as_uint(acc[S >> 1][rt][4 * q + 2] + t2_l) & 0x3fff3fffu; es.q2[1] = __float_as_uint(acc[S >> 1][rt][4 * q + 3]) & 0x3fff3fffu;
 #else
-          epi_all<false, true>(es, acc[S >> 1][rt], q, inv1_l, bv, t2_l);
+          epi_all<false, true, H3_EPI_FUSE>(es, acc[S >> 1][rt], q, inv1_l, bv, t2_l);
 #endif
           bfu[rt & 1][S][0][2 * jq] = es.q1[0]; bfu[rt & 1][S][0][2 * jq + 1] = es.q1[1];
           bfu[rt & 1][S][1][2 * jq] = es.q2[0]; bfu[rt & 1][S][1][2 * jq + 1] = es.q2[1];
@@ -695,7 +700,8 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
       f16x8 bf[4][2];
       {
         u32x4 bfu[4][2];
-        const float inv1_l = r_inv1[32 * rt + r] * kLog2e, t2_l = r_t2[32 * rt + r] * kLn2;
+        const float inv1_l = r_inv1[32 * rt + r] * kLog2e;
+        const float t2_l = H3_EPI_FUSE ? 1.0f / (r_t2[32 * rt + r] * kLn2) : r_t2[32 * rt + r] * kLn2;
 #pragma unroll
         for (int S = 0; S < 4; ++S)
 #pragma unroll
@@ -703,7 +709,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
             const int q = 2 * (S & 1) + jq;
             const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias1 + 64 * wave + 32 * (S >> 1) + 8 * q + 4 * hh);
             Epi4 es;
-            epi_all<false, true>(es, acc[S >> 1][rt], q, inv1_l, bv, t2_l);
+            epi_all<false, true, H3_EPI_FUSE>(es, acc[S >> 1][rt], q, inv1_l, bv, t2_l);
             bfu[S][0][2 * jq] = es.q1[0]; bfu[S][0][2 * jq + 1] = es.q1[1];
             bfu[S][1][2 * jq] = es.q2[0]; bfu[S][1][2 * jq + 1] = es.q2[1];
           }

@@ -65,7 +65,11 @@ struct Epi4 {
 // the exponential reads -y through its source modifier (no separate multiply: 7 instead of 8 instructions per value), and
 // the split's exact product y sigma(z) (tn ln 2) is swish(z) tn up to the float rounding of log2(e) ln 2 (1 - 2e-8).
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
-template <int K, bool PIN, bool PRE = false>
+// FUSE: the caller passes 1 / tn instead of tn and the lift rides in the reciprocal -- sigma(z) tn = 1 / ((1 + e) / tn), the
+// division by tn as the multiplier of ONE fma that also adds the 1 (stage 4) -- so the mixed-precision FMAs of the split form
+// z (sigma tn) themselves (exact inside the FMA) and the separate product z sigma (stage 7) is gone: 6 instead of 7 vector
+// instructions per activation (5 + the scaling in PRE's case).  e = inf (z -> -inf) gives sigma tn = 0, e = 0 gives tn.
+template <int K, bool PIN, bool PRE = false, bool FUSE = false>
 __device__ __forceinline__ void epi_stage(Epi4 &s, const f32x16 &d, int q, float inv, const f32x4 &bv, float tn) {
   if constexpr (PRE && K == 1) {
     // (nothing: the scaling is in inv / bv)
@@ -87,50 +91,56 @@ __device__ __forceinline__ void epi_stage(Epi4 &s, const f32x16 &d, int q, float
     if (PIN) asm volatile("" : "+v"(s.e[o]), "+v"(s.e[o + 1]));
   } else if constexpr (K == 4) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s.e[i] = 1.0f + s.e[i];
+    for (int i = 0; i < 4; ++i) s.e[i] = FUSE ? __builtin_fmaf(s.e[i], tn, tn) : 1.0f + s.e[i];
     if (PIN) asm volatile("" : "+v"(s.e[0]), "+v"(s.e[1]), "+v"(s.e[2]), "+v"(s.e[3]));
   } else if constexpr (K == 5 || K == 6) {
     constexpr int o = 2 * (K - 5);
     s.e[o] = __builtin_amdgcn_rcpf(s.e[o]); s.e[o + 1] = __builtin_amdgcn_rcpf(s.e[o + 1]);
     if (PIN) asm volatile("" : "+v"(s.e[o]), "+v"(s.e[o + 1]));
   } else if constexpr (K == 7) {
+    if constexpr (!FUSE) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s.z[i] = s.z[i] * s.e[i];
-    if (PIN) asm volatile("" : "+v"(s.z[0]), "+v"(s.z[1]), "+v"(s.z[2]), "+v"(s.z[3]));
+      for (int i = 0; i < 4; ++i) s.z[i] = s.z[i] * s.e[i];
+      if (PIN) asm volatile("" : "+v"(s.z[0]), "+v"(s.z[1]), "+v"(s.z[2]), "+v"(s.z[3]));
+    }
   } else if constexpr (K == 8) {
     s.q1[0] = s.q1[1] = 0u;
+    // the second factor of the split's products: the lift, or sigma tn of the value itself
+    const float m0 = FUSE ? s.e[0] : tn, m1 = FUSE ? s.e[1] : tn, m2 = FUSE ? s.e[2] : tn, m3 = FUSE ? s.e[3] : tn;
     // (hipcc pads no hazard behind an asm statement: where the pieces feed an MFMA straight from the registers -- the
     // tail, PIN == false -- the wait states between a VALU write and an MFMA's operand read stand inside the string)
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(s.q1[0]) : "v"(s.z[0]), "v"(tn));
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(s.q1[1]) : "v"(s.z[2]), "v"(tn));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(s.q1[0]) : "v"(s.z[0]), "v"(m0));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(s.q1[1]) : "v"(s.z[2]), "v"(m2));
     if constexpr (PIN) {
-      asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(s.q1[0]) : "v"(s.z[1]), "v"(tn));
-      asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(s.q1[1]) : "v"(s.z[3]), "v"(tn));
+      asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(s.q1[0]) : "v"(s.z[1]), "v"(m1));
+      asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(s.q1[1]) : "v"(s.z[3]), "v"(m3));
     } else {
-      asm("v_fma_mixhi_f16 %0, %1, %2, 0\n\ts_nop 1" : "+v"(s.q1[0]) : "v"(s.z[1]), "v"(tn));
-      asm("v_fma_mixhi_f16 %0, %1, %2, 0\n\ts_nop 1" : "+v"(s.q1[1]) : "v"(s.z[3]), "v"(tn));
+      asm("v_fma_mixhi_f16 %0, %1, %2, 0\n\ts_nop 1" : "+v"(s.q1[0]) : "v"(s.z[1]), "v"(m1));
+      asm("v_fma_mixhi_f16 %0, %1, %2, 0\n\ts_nop 1" : "+v"(s.q1[1]) : "v"(s.z[3]), "v"(m3));
     }
     if (PIN) asm volatile("" : "+v"(s.q1[0]), "+v"(s.q1[1]));
   } else if constexpr (K == 9) {
     s.q2[0] = s.q2[1] = 0u;
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(s.q2[0]) : "v"(s.z[0]), "v"(tn), "v"(s.q1[0]));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(s.q2[1]) : "v"(s.z[2]), "v"(tn), "v"(s.q1[1]));
+    const float m0 = FUSE ? s.e[0] : tn, m1 = FUSE ? s.e[1] : tn, m2 = FUSE ? s.e[2] : tn, m3 = FUSE ? s.e[3] : tn;
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(s.q2[0]) : "v"(s.z[0]), "v"(m0), "v"(s.q1[0]));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(s.q2[1]) : "v"(s.z[2]), "v"(m2), "v"(s.q1[1]));
     if constexpr (PIN) {
-      asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(s.q2[0]) : "v"(s.z[1]), "v"(tn), "v"(s.q1[0]));
-      asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(s.q2[1]) : "v"(s.z[3]), "v"(tn), "v"(s.q1[1]));
+      asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(s.q2[0]) : "v"(s.z[1]), "v"(m1), "v"(s.q1[0]));
+      asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(s.q2[1]) : "v"(s.z[3]), "v"(m3), "v"(s.q1[1]));
     } else {
-      asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\ts_nop 1" : "+v"(s.q2[0]) : "v"(s.z[1]), "v"(tn), "v"(s.q1[0]));
-      asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\ts_nop 1" : "+v"(s.q2[1]) : "v"(s.z[3]), "v"(tn), "v"(s.q1[1]));
+      asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\ts_nop 1" : "+v"(s.q2[0]) : "v"(s.z[1]), "v"(m1), "v"(s.q1[0]));
+      asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\ts_nop 1" : "+v"(s.q2[1]) : "v"(s.z[3]), "v"(m3), "v"(s.q1[1]));
     }
     if (PIN) asm volatile("" : "+v"(s.q2[0]), "+v"(s.q2[1]));
   }
 }
-template <bool PIN, bool PRE = false>
+template <bool PIN, bool PRE = false, bool FUSE = false>
 __device__ __forceinline__ void epi_all(Epi4 &s, const f32x16 &d, int q, float inv, const f32x4 &bv, float tn) {
-  epi_stage<0, PIN, PRE>(s, d, q, inv, bv, tn); epi_stage<1, PIN, PRE>(s, d, q, inv, bv, tn); epi_stage<2, PIN, PRE>(s, d, q, inv, bv, tn);
-  epi_stage<3, PIN, PRE>(s, d, q, inv, bv, tn); epi_stage<4, PIN, PRE>(s, d, q, inv, bv, tn); epi_stage<5, PIN, PRE>(s, d, q, inv, bv, tn);
-  epi_stage<6, PIN, PRE>(s, d, q, inv, bv, tn); epi_stage<7, PIN, PRE>(s, d, q, inv, bv, tn); epi_stage<8, PIN, PRE>(s, d, q, inv, bv, tn);
-  epi_stage<9, PIN, PRE>(s, d, q, inv, bv, tn);
+  epi_stage<0, PIN, PRE, FUSE>(s, d, q, inv, bv, tn); epi_stage<1, PIN, PRE, FUSE>(s, d, q, inv, bv, tn);
+  epi_stage<2, PIN, PRE, FUSE>(s, d, q, inv, bv, tn); epi_stage<3, PIN, PRE, FUSE>(s, d, q, inv, bv, tn);
+  epi_stage<4, PIN, PRE, FUSE>(s, d, q, inv, bv, tn); epi_stage<5, PIN, PRE, FUSE>(s, d, q, inv, bv, tn);
+  epi_stage<6, PIN, PRE, FUSE>(s, d, q, inv, bv, tn); epi_stage<7, PIN, PRE, FUSE>(s, d, q, inv, bv, tn);
+  epi_stage<8, PIN, PRE, FUSE>(s, d, q, inv, bv, tn); epi_stage<9, PIN, PRE, FUSE>(s, d, q, inv, bv, tn);
 }
 
 

@@ -257,6 +257,17 @@ extern "C" int cmbpo_rollout_run(cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *p
     } else if (d_slot != nullptr) {
       const uint32_t *h_slot = mir.h + (size_t)slot * kMirrorDwords;
       if (int rc2 = cmbpo_internal_scalars_mirror(r, d_slot, seq, stream)) return rc2;
+      // large batches (no rider in the critics' launch): the actor for the next step goes out BEHIND the counters and ahead of
+      // the host's wait for them -- it needs neither (it evaluates every row this step stepped, outputs slot indexed, exactly
+      // what the rider does), and the host's round trip hides behind it
+      static const bool early_actor = !(getenv("CMBPO_EARLY_ACTOR") && getenv("CMBPO_EARLY_ACTOR")[0] == '0');
+      if (early_actor && eps_next != nullptr && !ready && r->ptr + 1 < r->T) {
+        auto w = [](const float *q) { return const_cast<float *>(q); };
+        if (int rc2 = cmbpo_policy_forward(policy, r->next_obs, r->obs_dim, eps_next, r->alive_idx, nullptr, n_alive, w(r->act_t),
+                                           w(r->logp_t), w(r->mu_t), w(r->ls_t), stream))
+          return rc2;
+        ready = true;
+      }
       if (int rc2 = wait_mirror(h_slot, seq, (hipStream_t)stream)) return rc2;
       memcpy(h, h_slot, 384);
     } else if (int rc2 = cmbpo_rollout_read_scalars(r, h, stream)) {         // the host sync of the step

@@ -257,7 +257,7 @@ def get_roofline(w, get_events):
     n = [k for _, _, _, k in get_events]
     achieved = per_sample * float(np.sum(n)) / (float(np.sum(fl_ms)) * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-            "kernel": "flatten_vec_kernel + flatten_scalar_kernel", "flatten_us": float(np.mean(fl_ms)) * 1e3,
+            "kernel": "flatten_kernel (vector-field tiles + scalar-field tiles in one launch)", "flatten_us": float(np.mean(fl_ms)) * 1e3,
             "get_us_offsets_to_flatten": float(np.mean(all_ms)) * 1e3, "bytes_per_sample": per_sample,
             "samples": float(np.mean(n))}
 
@@ -650,7 +650,7 @@ def main():
     roof = ens_roofline(w, events)
     # HBM traffic of the dominant kernel from PMC counters collected OFFLINE (separate rocprofv3 --pmc passes, see the
     # json file), scaled to this run's rows per launch -- not a measurement of this run
-    pmc_file = {"ens_h3": ("r02", "pmc_traffic_h3.json"), "ens_split": ("r01", "pmc_traffic_split.json"),
+    pmc_file = {"ens_h3": ("r03", "pmc_traffic_h3.json"), "ens_split": ("r01", "pmc_traffic_split.json"),
                 "ens_mlp": ("r01", "pmc_traffic.json")}[roof["kernel"].split("_kernel")[0]] if roof else None
     if roof is not None:
         roof["traffic"] = None

@@ -955,8 +955,8 @@ __device__ __forceinline__ void flat_vec_out(const float *tile, float *dst, int 
   }
 }
 
-__global__ __launch_bounds__(256) void flatten_vec_kernel(const cmbpo_rollout_t r, const int32_t *offs, const FlatArgs fa,
-                                                          int vt, int Tt) {
+__device__ __forceinline__ void flatten_vec_body(const cmbpo_rollout_t &r, const int32_t *offs, const FlatArgs &fa, int vt, int Tt,
+                                                 int blk) {
   // Tt = the steps the rollout took (<= r.T): no path is longer, so the tiles are laid out -- and the LDS sized -- for Tt
   // steps (an 'uncertainty' rollout that ended after 5 of 34 steps: 9 KB per workgroup instead of 63, eight workgroups
   // per CU instead of two)
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256) void flatten_vec_kernel(const cmbpo_rollout_t 
   __shared__ int lens[kVecTile], loffs[kVecTile + 1];
   // (behind the tiles: output position inside the tile's block -> bl * Tt + t, vt * Tt entries)
   unsigned short *smap = reinterpret_cast<unsigned short *>(tile + (size_t)vt * Tt * max(r.obs_dim, 3 * r.act_dim));
-  const int b0 = blockIdx.x * vt;
+  const int b0 = blk * vt;
   const int nb = min(r.B - b0, vt);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < kVecTile) lens[tid] = tid < nb ? r.len[b0 + tid] : 0;
@@ -1002,11 +1002,11 @@ __global__ __launch_bounds__(256) void flatten_vec_kernel(const cmbpo_rollout_t 
 // ROWS branches per workgroup: 64 (16 lanes x 16 bytes cover a step's row of the tile), or 16 for buffers too small to give
 // every CU a 64-branch tile (10 000 branches are 157 tiles of 64 on 256 CUs)
 template <int ROWS>
-__global__ __launch_bounds__(256) void flatten_scalar_kernel(const cmbpo_rollout_t r, const int32_t *offs, const double *st,
-                                                             const FlatArgs fa, int Tt) {
+__device__ __forceinline__ void flatten_scalar_body(const cmbpo_rollout_t &r, const int32_t *offs, const double *st,
+                                                    const FlatArgs &fa, int Tt, int blk) {
   extern __shared__ float tile[];          // [8][ROWS][Tt + 1] | position map [ROWS * Tt] (ushort)
   __shared__ int loffs[ROWS + 1];
-  const int b0 = blockIdx.x * ROWS;
+  const int b0 = blk * ROWS;
   const int nb = min(r.B - b0, ROWS);
   const int tid = threadIdx.x;
   if (tid <= ROWS) loffs[tid] = offs[min(b0 + tid, r.B)];
@@ -1307,6 +1307,18 @@ extern "C" int cmbpo_buffer_prepare(const cmbpo_rollout_t *r, int32_t *d_offsets
   return CMBPO_OK;
 }
 
+// Both halves of the flatten in ONE launch: the first n_vec workgroups carry the vector fields' tiles, the rest the eight scalar
+// fields' (two launches of ~10 us each around 20-40 us of copying at the shipped configurations' 1e4 branches; the scalar tiles
+// fill the CUs the vector tiles leave).  Dynamic LDS: the larger of the two layouts.
+namespace {
+template <int ROWS>
+__global__ __launch_bounds__(256) void flatten_kernel(const cmbpo_rollout_t r, const int32_t *offs, const double *st, const FlatArgs fa,
+                                                      int vt, int Tt, int n_vec) {
+  if ((int)blockIdx.x < n_vec) flatten_vec_body(r, offs, fa, vt, Tt, (int)blockIdx.x);
+  else flatten_scalar_body<ROWS>(r, offs, st, fa, Tt, (int)blockIdx.x - n_vec);
+}
+}  // namespace
+
 extern "C" int cmbpo_buffer_flatten(const cmbpo_rollout_t *r, const int32_t *d_offsets, const double *d_stats,
                                     float *const *h_out12, void *stream) {
   if (int rc = check_rollout(r, "cmbpo_buffer_flatten")) return rc;
@@ -1338,25 +1350,22 @@ extern "C" int cmbpo_buffer_flatten(const cmbpo_rollout_t *r, const int32_t *d_o
   const size_t lds_v = (size_t)vt * Tt * dtile * sizeof(float) + (((size_t)vt * Tt * sizeof(unsigned short) + 15) & ~(size_t)15);
   const size_t lds_s = (size_t)8 * rows * (Tt + 1) * sizeof(float) + (size_t)rows * Tt * sizeof(unsigned short);
   CMBPO_REQUIRE(lds_v <= 150 * 1024 && lds_s <= 150 * 1024, "cmbpo_buffer_flatten: T = %d, dim = %d exceed the LDS tiles", Tt, dmax);
-  static size_t attr_v = 64 * 1024, attr_s = 64 * 1024;
-  if (lds_v > attr_v) {
-    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(flatten_vec_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v));
-    attr_v = lds_v;
+  const size_t lds = lds_v > lds_s ? lds_v : lds_s;
+  static size_t attr = 64 * 1024;
+  if (lds > attr) {
+    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(flatten_kernel<kFlatRows>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(flatten_kernel<16>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = lds;
   }
-  if (lds_s > attr_s) {
-    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(flatten_scalar_kernel<kFlatRows>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(flatten_scalar_kernel<16>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-    attr_s = lds_s;
-  }
-  hipLaunchKernelGGL(flatten_vec_kernel, dim3(cmbpo_ceil_div(r->B, vt)), dim3(256), lds_v, s, *r, d_offsets, fa, vt, Tt);
+  const int n_vec = cmbpo_ceil_div(r->B, vt);
   if (rows == 16)
-    hipLaunchKernelGGL(flatten_scalar_kernel<16>, dim3(cmbpo_ceil_div(r->B, 16)), dim3(256), lds_s, s, *r, d_offsets, d_stats, fa, Tt);
+    hipLaunchKernelGGL(flatten_kernel<16>, dim3(n_vec + cmbpo_ceil_div(r->B, 16)), dim3(256), lds, s, *r, d_offsets, d_stats, fa, vt, Tt,
+                       n_vec);
   else
-    hipLaunchKernelGGL(flatten_scalar_kernel<kFlatRows>, dim3(cmbpo_ceil_div(r->B, kFlatRows)), dim3(256), lds_s, s, *r, d_offsets,
-                       d_stats, fa, Tt);
+    hipLaunchKernelGGL(flatten_kernel<kFlatRows>, dim3(n_vec + cmbpo_ceil_div(r->B, kFlatRows)), dim3(256), lds, s, *r, d_offsets,
+                       d_stats, fa, vt, Tt, n_vec);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }

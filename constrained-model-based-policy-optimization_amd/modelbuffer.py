@@ -224,6 +224,22 @@ class ModelBuffer:
         if getattr(self, "get_events", None) is not None:    # bench.py: HIP events around get()'s kernels
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
                   torch.cuda.Event(enable_timing=True))
+        # the number of stored samples is the pool's size counter, read with the step counters: no device round trip here --
+        # and the output block is sized and split BEFORE the first launch, so that the scan / moment launches and the flatten
+        # follow each other on the stream without the interpreter between them
+        n = int(self._size)
+        D, A, dev = self.obs_dim, self.act_dim, self.device
+        dims = [D, A, 0, 0, 0, 0, 0, 0, 0, 0, A, A]
+        # one allocation for the twelve arrays (each starts on a 256-byte boundary) and one split: the list holds views of it
+        sizes = []
+        for d in dims:
+            m = n * max(d, 1)
+            sizes += [m, -m % 64]
+        flat = torch.empty(max(sum(sizes), 1), dtype=torch.float32, device=dev)
+        parts = flat.split_with_sizes(sizes)[0::2] if n > 0 else [flat[:0]] * 12
+        outs = [p_.view(n, d) if d else p_ for p_, d in zip(parts, dims)]
+        ptrs = (C.c_void_p * 12)(*[o.data_ptr() for o in outs])
+        if ev is not None:
             ev[0].record()
         sharded = self.comm is not None and self.comm.world > 1
         if sharded:
@@ -237,20 +253,7 @@ class ModelBuffer:
         else:
             # one GPU: the scan and both moment passes as two launches
             self._call("cmbpo_buffer_prepare", t["offsets"].data_ptr(), t["stats"].data_ptr())
-        # the number of stored samples is the pool's size counter, read with the step counters: no device round trip here
-        n = int(self._size)
-        D, A, dev = self.obs_dim, self.act_dim, self.device
-        dims = [D, A, 0, 0, 0, 0, 0, 0, 0, 0, A, A]
-        # one allocation for the twelve arrays (each starts on a 256-byte boundary) and one split: the list holds views of it
-        sizes = []
-        for d in dims:
-            m = n * max(d, 1)
-            sizes += [m, -m % 64]
-        flat = torch.empty(max(sum(sizes), 1), dtype=torch.float32, device=dev)
-        parts = flat.split_with_sizes(sizes)[0::2] if n > 0 else [flat[:0]] * 12
-        outs = [p_.view(n, d) if d else p_ for p_, d in zip(parts, dims)]
         if n > 0:
-            ptrs = (C.c_void_p * 12)(*[o.data_ptr() for o in outs])
             if ev is not None:
                 ev[1].record()
             self._call("cmbpo_buffer_flatten", t["offsets"].data_ptr(), t["stats"].data_ptr(), ptrs)

@@ -571,7 +571,7 @@ extern "C" int cmbpo_mlp_create(cmbpo_mlp_t **out, int ensemble, int in_dim, int
   CMBPO_REQUIRE(out != nullptr, "cmbpo_mlp_create: out is NULL");
   CMBPO_REQUIRE(ensemble >= 1 && ensemble <= 64, "cmbpo_mlp_create: ensemble %d out of range", ensemble);
   CMBPO_REQUIRE(in_dim >= 1 && in_dim <= 256, "cmbpo_mlp_create: in_dim %d out of range", in_dim);
-  CMBPO_REQUIRE(hidden == 128 || hidden == 512, "cmbpo_mlp_create: hidden must be 128 or 512 (got %d)", hidden);
+  CMBPO_REQUIRE(hidden == 128 || hidden == 256 || hidden == 512, "cmbpo_mlp_create: hidden must be 128, 256 or 512 (got %d)", hidden);
   CMBPO_REQUIRE(out_width >= 1 && out_width <= 128, "cmbpo_mlp_create: out_width %d out of range", out_width);
   CMBPO_REQUIRE(activation == CMBPO_ACT_SWISH || activation == CMBPO_ACT_TANH, "cmbpo_mlp_create: bad activation %d", activation);
   CMBPO_REQUIRE(head >= CMBPO_HEAD_PROB && head <= CMBPO_HEAD_GAUSS_PI, "cmbpo_mlp_create: bad head %d", head);
@@ -785,15 +785,19 @@ int launch_mlp(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s, int head_override 
   if (head == CMBPO_HEAD_TRAIN && m->act == CMBPO_ACT_SWISH) {
     if (H == 512) CMBPO_LAUNCH(512, 1, CMBPO_ACT_SWISH, CMBPO_HEAD_TRAIN);
     if (H == 128) CMBPO_LAUNCH(128, 1, CMBPO_ACT_SWISH, CMBPO_HEAD_TRAIN);
+    if (H == 256) CMBPO_LAUNCH(256, 1, CMBPO_ACT_SWISH, CMBPO_HEAD_TRAIN);
   } else if (head == CMBPO_HEAD_PROB && m->act == CMBPO_ACT_SWISH) {
     if (H == 512 && BT == 1) CMBPO_LAUNCH(512, 1, CMBPO_ACT_SWISH, CMBPO_HEAD_PROB);
     if (H == 512 && BT == 2) CMBPO_LAUNCH(512, 2, CMBPO_ACT_SWISH, CMBPO_HEAD_PROB);
     if (H == 128) CMBPO_LAUNCH(128, 1, CMBPO_ACT_SWISH, CMBPO_HEAD_PROB);
+    if (H == 256) CMBPO_LAUNCH(256, 1, CMBPO_ACT_SWISH, CMBPO_HEAD_PROB);
   } else if (head == CMBPO_HEAD_DETMEAN && m->act == CMBPO_ACT_SWISH) {
     if (H == 128) CMBPO_LAUNCH(128, 1, CMBPO_ACT_SWISH, CMBPO_HEAD_DETMEAN);
+    if (H == 256) CMBPO_LAUNCH(256, 1, CMBPO_ACT_SWISH, CMBPO_HEAD_DETMEAN);   // (configs/baseconfig/base.py:16,19: the default critic width)
     if (H == 512) CMBPO_LAUNCH(512, 1, CMBPO_ACT_SWISH, CMBPO_HEAD_DETMEAN);
   } else if (head == CMBPO_HEAD_GAUSS_PI && m->act == CMBPO_ACT_TANH) {
     if (H == 128) CMBPO_LAUNCH(128, 1, CMBPO_ACT_TANH, CMBPO_HEAD_GAUSS_PI);
+    if (H == 256) CMBPO_LAUNCH(256, 1, CMBPO_ACT_TANH, CMBPO_HEAD_GAUSS_PI);    // (base.py:7: the default policy width)
     if (H == 512) CMBPO_LAUNCH(512, 1, CMBPO_ACT_TANH, CMBPO_HEAD_GAUSS_PI);
   }
 #undef CMBPO_LAUNCH

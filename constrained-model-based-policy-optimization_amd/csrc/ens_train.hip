@@ -1757,7 +1757,7 @@ extern "C" int cmbpo_trainer_step(cmbpo_trainer_t *t, const float *d_inputs, int
   }
   const size_t lds = ((size_t)H / 4 * 32 + (size_t)t->OPk / 4 * 32) * sizeof(f32x4);
   const int tiles = cmbpo_ceil_div(batch, 32);
-  rc = (H == 512) ? launch_bwd<512>(b, tiles, E, lds, s) : launch_bwd<128>(b, tiles, E, lds, s);
+  rc = (H == 512) ? launch_bwd<512>(b, tiles, E, lds, s) : (H == 256 ? launch_bwd<256>(b, tiles, E, lds, s) : launch_bwd<128>(b, tiles, E, lds, s));
   if (rc != CMBPO_OK) return rc;
 
   if (H == 512) {

@@ -71,6 +71,8 @@ CASES = [  # E, I, H, D, loss, batch
     (2, 100, 128, 2, "MSE", 40),     # input too wide for the fused kernel: the general path on a deterministic head
     (7, 37, 512, 30, "NLL", 256),    # the class-default loss of PE on the dynamics shapes
     (3, 11, 128, 4, "NLL", 100),
+    (3, 29, 256, 1, "MSE", 100),     # the base config's default critic width (configs/baseconfig/base.py:16,19): the general path
+    (4, 20, 256, 6, "MSPE", 150),    # ... and a probabilistic ensemble of that width
 ]
 
 

@@ -115,6 +115,50 @@ def test_ens_forward_no_scalers_hidden128(hip_lib):
     np.testing.assert_allclose(var, rvar, rtol=1e-3, atol=1e-7)
 
 
+@pytest.mark.parametrize("n", [1, 100, 4097])
+def test_width_256_forward_heads(hip_lib, n):
+    """Hidden width 256 (the base config's default for the policy and both critics, configs/baseconfig/base.py:7,16,19; every
+    shipped experiment overrides it to 128): the three heads of the forward on the general fp32-MFMA kernel."""
+    _cuda()
+    from cmbpo_amd import synthetic
+    from cmbpo_amd.pens import PE
+    from cmbpo_amd.cpo_policy import GaussianActor
+    rng = np.random.default_rng(256 + n)
+    H, obs_dim, act_dim, E = 256, 29, 8, 3
+    x = rng.standard_normal((n, obs_dim)).astype(np.float32)
+    # a critic (mean over all members)
+    ws, bs = synthetic.ensemble_weights(rng, E, obs_dim, H, 1, bias_scale=0.1)
+    sc_in, sc_out = synthetic.scaler(rng, obs_dim), synthetic.scaler(rng, 1, hit_clamp=False)
+    v = PE(obs_dim, 1, hidden_dims=(H, H), num_networks=E, num_elites=2, loss="MSE", use_scaler_in=True, use_scaler_out=True,
+           device="cuda:0")
+    v.set_weights(ws, bs, sc_in, sc_out)
+    np.testing.assert_allclose(v.predict(x), refcpu.ens_predict_mean(x, ws, bs, sc_in, sc_out), rtol=1e-4, atol=1e-4)
+    # a probabilistic ensemble
+    O = 11
+    ws, bs = synthetic.ensemble_weights(rng, E, obs_dim, H, 2 * O, bias_scale=0.1)
+    m = PE(obs_dim, O, hidden_dims=(H, H), num_networks=E, num_elites=2, loss="MSPE", device="cuda:0")
+    m.set_weights(ws, bs)
+    mean, var = m.predict_ensemble(x)
+    rmean, rvar = refcpu.ens_forward(x, ws, bs)
+    np.testing.assert_allclose(mean, rmean, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(var, rvar, rtol=1e-3, atol=1e-7)
+    # the actor
+    shapes = [(obs_dim, H), (H,), (H, H), (H,), (H, act_dim), (act_dim,), (act_dim,)]
+    params = [(rng.standard_normal(sh) * (1.0 / np.sqrt(sh[0]) if len(sh) == 2 else 0.1)).astype(np.float32) for sh in shapes]
+    params[6] = rng.uniform(-1.0, 0.0, act_dim).astype(np.float32)
+    actor = GaussianActor(obs_dim, act_dim, (H, H), device="cuda:0")
+    actor.set_params(params)
+    eps = rng.standard_normal((n, act_dim)).astype(np.float32)
+    dev = actor.device
+    f = dict(dtype=torch.float32, device=dev)
+    out = dict(pi=torch.empty((n, act_dim), **f), logp_pi=torch.empty(n, **f), mu=torch.empty((n, act_dim), **f),
+               log_std=torch.empty((n, act_dim), **f))
+    actor.forward_device(torch.from_numpy(x).to(dev), torch.from_numpy(eps).to(dev), out)
+    ref = refcpu.policy_forward(x, params, eps)
+    for k in ("pi", "mu", "logp_pi", "log_std"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=1e-4, atol=1e-4, err_msg=k)
+
+
 def test_ens_forward_row_gather_and_split_inputs(hip_lib):
     """obs/act passed separately, rows addressed through an index list into branch slots."""
     dev = _cuda()

@@ -96,7 +96,7 @@ int cmbpo_set_ens_f16_row_tiles(int rt);
  * ------------------------------------------------------------------------ */
 typedef struct cmbpo_mlp cmbpo_mlp_t;
 
-/* hidden must be 128 or 512.  out_width is the network's last-layer width
+/* hidden must be 128, 256 or 512 (256: the general fp32-MFMA kernels only).  out_width is the network's last-layer width
  * (2*out_dim for HEAD_PROB, out_dim otherwise), <= 128. */
 int cmbpo_mlp_create(cmbpo_mlp_t **out, int ensemble, int in_dim, int hidden,
                      int out_width, int activation, int head);

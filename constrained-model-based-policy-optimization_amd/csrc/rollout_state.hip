@@ -236,7 +236,12 @@ __device__ __forceinline__ void gae_finish_path(const cmbpo_rollout_t &r, int b,
 }
 
 // ---- finish: reward + cost GAE, then mark terminated (modelbuffer.py:138-182) -------------------
-__global__ __launch_bounds__(256) void finish_kernel(const cmbpo_rollout_t r, int mode) {
+__device__ __forceinline__ void store_stats_body(const cmbpo_rollout_t &r);
+// fold_stats (the rollout step at large batches, mode 1): workgroup 0 first folds the sums store_kernel's tiles left -- the
+// store is a launch further back, so no atomics are needed, and nothing before the end of this kernel reads the accumulators
+// (a launch of its own until round 3: store_stats_kernel)
+__global__ __launch_bounds__(256) void finish_kernel(const cmbpo_rollout_t r, int mode, int fold_stats) {
+  if (fold_stats && blockIdx.x == 0) store_stats_body(r);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = r.iscal[CMBPO_I_N_ALIVE];
   if (i >= n) return;
@@ -346,8 +351,8 @@ __global__ __launch_bounds__(256) void store_kernel(const cmbpo_rollout_t r) {
   }
 }
 
-// fold the per-tile sums of store_kernel into the counters / accumulators (one workgroup, fixed order)
-__global__ __launch_bounds__(256) void store_stats_kernel(const cmbpo_rollout_t r) {
+// fold the per-tile sums of store_kernel into the counters / accumulators (the 256 threads of one workgroup, fixed order)
+__device__ __forceinline__ void store_stats_body(const cmbpo_rollout_t &r) {
   __shared__ double sm_d[16];
   const int n = r.iscal[CMBPO_I_N_ALIVE];
   const int n_wg = (n + kStoreRows - 1) / kStoreRows;
@@ -382,6 +387,8 @@ __global__ __launch_bounds__(256) void store_stats_kernel(const cmbpo_rollout_t 
     r.dscal[CMBPO_D_MAX_PATH_RETURN] = fmax(r.dscal[CMBPO_D_MAX_PATH_RETURN], s[7]);
   }
 }
+
+__global__ __launch_bounds__(256) void store_stats_kernel(const cmbpo_rollout_t r) { store_stats_body(r); }
 
 // ---- small rollout batches: decide -> finish(PRE) -> store -> statistics as ONE workgroup --------------------------------
 // At the shipped configurations' 1e3 - 1e4 branches each of the five kernels above is a few microseconds of work behind a
@@ -1125,7 +1132,7 @@ extern "C" int cmbpo_rollout_finish(const cmbpo_rollout_t *r, int mode, void *st
                 "cmbpo_rollout_finish: NULL buffer");
   if (mode == 1) CMBPO_REQUIRE(r->v_n && r->vc_n && r->term_t, "cmbpo_rollout_finish: POST needs v_n, vc_n, term_t");
   else CMBPO_REQUIRE(r->v_t && r->vc_t, "cmbpo_rollout_finish: needs v_t, vc_t");
-  hipLaunchKernelGGL(finish_kernel, dim3(cmbpo_ceil_div(r->B, 256)), dim3(256), 0, (hipStream_t)stream, *r, mode);
+  hipLaunchKernelGGL(finish_kernel, dim3(cmbpo_ceil_div(r->B, 256)), dim3(256), 0, (hipStream_t)stream, *r, mode, 0);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }
@@ -1142,6 +1149,28 @@ extern "C" int cmbpo_rollout_store(const cmbpo_rollout_t *r, void *stream) {
   CMBPO_REQUIRE(r->store_part != nullptr, "cmbpo_rollout_store: NULL store_part scratch");
   hipLaunchKernelGGL(store_kernel, dim3(cmbpo_ceil_div(r->B, kStoreRows)), dim3(256), 0, (hipStream_t)stream, *r);
   hipLaunchKernelGGL(store_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *r);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+// the rollout step at large batches: the store without its statistics launch, and the finish(POST) that folds them
+int cmbpo_internal_store_nostats(const cmbpo_rollout_t *r, void *stream) {
+  if (int rc = check_rollout(r, "cmbpo_rollout_store")) return rc;
+  CMBPO_REQUIRE(r->ptr < r->T, "cmbpo_rollout_store: buffer full (ptr %d == T)", r->ptr);
+  CMBPO_REQUIRE(r->cur_obs && r->act_t && r->logp_t && r->mu_t && r->ls_t && r->v_t && r->vc_t && r->rew_t && r->cost_t && r->dkl_t &&
+                    r->epv_t && r->obs_buf && r->act_buf && r->mu_buf && r->ls_buf && r->rew_buf && r->val_buf && r->cost_buf &&
+                    r->cval_buf && r->logp_buf && r->store_part,
+                "cmbpo_rollout_store: NULL array");
+  hipLaunchKernelGGL(store_kernel, dim3(cmbpo_ceil_div(r->B, kStoreRows)), dim3(256), 0, (hipStream_t)stream, *r);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+int cmbpo_internal_finish_post_fold(const cmbpo_rollout_t *r, void *stream) {
+  if (int rc = check_rollout(r, "cmbpo_rollout_finish")) return rc;
+  CMBPO_REQUIRE(r->v_n && r->vc_n && r->term_t && r->rew_buf && r->val_buf && r->cost_buf && r->cval_buf && r->adv_buf && r->ret_buf &&
+                    r->cadv_buf && r->cret_buf && r->store_part,
+                "cmbpo_rollout_finish (POST): NULL array");
+  hipLaunchKernelGGL(finish_kernel, dim3(cmbpo_ceil_div(r->B, 256)), dim3(256), 0, (hipStream_t)stream, *r, 1, 1);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }

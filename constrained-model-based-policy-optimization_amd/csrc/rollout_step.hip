@@ -17,6 +17,8 @@ int cmbpo_internal_book_post_mirror(const cmbpo_rollout_t *r, int n_alive, uint3
                                     double stop_total, void *stream);
 int cmbpo_internal_scalars_mirror(const cmbpo_rollout_t *r, uint32_t *d_host_out, uint32_t seq, void *stream);
 int cmbpo_internal_book_pre_spec(const cmbpo_rollout_t *r, int n_alive, void *stream);
+int cmbpo_internal_store_nostats(const cmbpo_rollout_t *r, void *stream);
+int cmbpo_internal_finish_post_fold(const cmbpo_rollout_t *r, void *stream);
 int cmbpo_internal_spec_words(const cmbpo_rollout_t *r, int begin, void *stream);
 
 // A step enqueued AHEAD of the previous step's counters (cmbpo_rollout_run, small batches): n_alive is then an upper bound (the
@@ -61,9 +63,14 @@ static int step_impl(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy,
   } else if (n_alive <= cmbpo_rollout_book_pre_max_rows() && !r->use_host_budget) {
     if ((rc = cmbpo_rollout_book_pre(r, n_alive, stream))) return rc;     // decide + finish(PRE) + store in one launch
   } else {
+    // large batches.  No branch can finish before the store unless the uncertainty test or a sample budget is on; the step's
+    // sums are folded by the first workgroup of finish(POST) below instead of a launch of their own (nothing reads the
+    // accumulators in between).  The budget exchange across shards reads them on the host: it keeps the separate launches.
+    const bool fold_late = !r->use_host_budget;
     if ((rc = cmbpo_rollout_decide(r, stream))) return rc;
-    if ((rc = cmbpo_rollout_finish(r, 0, stream))) return rc;
-    if ((rc = cmbpo_rollout_store(r, stream))) return rc;
+    if (r->uncertainty_mode || r->max_samples != 0 || r->use_host_budget)
+      if ((rc = cmbpo_rollout_finish(r, 0, stream))) return rc;
+    if ((rc = fold_late ? cmbpo_internal_store_nostats(r, stream) : cmbpo_rollout_store(r, stream))) return rc;
   }
   if (cmbpo_critic_pair_supported(v, vc)) {      // both critics in one launch (csrc/critic_f16.hip)
     // ... and, where it fits, the actor for the next step as one more wave per tile: both read next_obs, the store above has
@@ -88,7 +95,7 @@ static int step_impl(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy,
       return rc;
     return 1;                                                              // the alive list has been rebuilt: swap it
   }
-  return cmbpo_rollout_finish(r, 1, stream);
+  return r->use_host_budget ? cmbpo_rollout_finish(r, 1, stream) : cmbpo_internal_finish_post_fold(r, stream);
 }
 
 extern "C" int cmbpo_rollout_step(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy, cmbpo_mlp_t *model,

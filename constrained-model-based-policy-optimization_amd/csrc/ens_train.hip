@@ -278,6 +278,285 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdArgs p)
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The backward chain of a 512-wide ensemble on the f16 matrix path (three v_mfma_f32_32x32x16_f16 per float32 product on
+// two-piece operands, f16_split.h; arithmetic and lifts as in ens_h3.hip).  The fp32 kernel above walks 32-row tiles, two
+// workgroups per CU: every tile streams the member's 1 MB of W1^T from L2 -- 470 MB per step at batch 2048, which is what
+// its 111 us are.  Here an item is 64 rows of one member on 8 waves (one workgroup per CU, one round of items at batch
+// 2048): half the weight stream per row, the products at the f16 pipe's rate.
+//   d3 (computed while the tile is staged, as above) -> fp32 tile in LDS -> the row's lift from its largest magnitude ->
+//   two-piece f16 image [row][k] -> d2 = (d3 W2^T) * g2 (A = the W2^T image from L2, wave w owns n-tiles 2 w, 2 w + 1 x both
+//   row tiles) -> stored, and split into the [64][512] two-piece image under a lift known before the product (|d2| <=
+//   1.1 max |W2| OPk max |d3[row]|) -> d1 = (d2 W1^T) * g1 (A fragments a slab ahead through a three-slot ring) -> stored.
+// ------------------------------------------------------------------------------------------------------------
+struct BwdHArgs {
+  BwdArgs b;
+  const f16x8 *w2t, *w1t;          // images [member][n-tile 16][k-slab][piece 2][lane 64] of 8 halves
+  size_t w2t_stride, w1t_stride;    // per member, 16-byte units
+  const float *stats;               // [E][NSTAT]: the weights' lift of layer l at [4 l], max |W| at [4 l + 3]
+  int s3;                           // k-slabs of the first product (OPk <= 16 s3)
+  int tiles32;                      // 32-row tiles of the batch (the per-tile maxima are indexed by those)
+};
+
+constexpr int kBhThreads = 512, kBhRows = 64, kBhHid = 512;
+constexpr int kBhD2Str = kBhHid + 8;      // halves per row of the d2 image: 16-byte slots per row odd -> conflict-free reads
+__host__ __device__ constexpr int bh_d3str(int s3) { return 16 * s3 + 8; }
+__host__ __device__ constexpr size_t bh_lds_bytes(int s3) {
+  return (size_t)2 * kBhRows * kBhD2Str * 2 + (size_t)2 * kBhRows * bh_d3str(s3) * 2 + (size_t)4 * kBhRows * 4;
+}
+
+__global__ __launch_bounds__(kBhThreads) void bwd_chain_h_kernel(const BwdHArgs a) {
+  const BwdArgs &p = a.b;
+  extern __shared__ f32x4 smem[];
+  _Float16 *d2img = reinterpret_cast<_Float16 *>(smem);                         // [2 pieces][64][kBhD2Str]
+  float *d3f = reinterpret_cast<float *>(smem);                                 // [64][OPk] fp32 (aliases d2img: consumed first)
+  _Float16 *d3img = d2img + (size_t)2 * kBhRows * kBhD2Str;                     // [2 pieces][64][D3S]
+  const int D3S = bh_d3str(a.s3);
+  float *r_inv3 = reinterpret_cast<float *>(d3img + (size_t)2 * kBhRows * D3S); // [64] 1 / (s2 t3)
+  float *r_t3 = r_inv3 + kBhRows, *r_t2 = r_t3 + kBhRows, *r_inv2 = r_t2 + kBhRows;
+  __shared__ unsigned s_rowmax[kBhRows];
+  __shared__ float s_dmax[3][kBhThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int e = blockIdx.y, row0 = blockIdx.x * kBhRows;
+  const float *st = a.stats + (size_t)e * NSTAT;
+  if (tid < kBhRows) s_rowmax[tid] = 0u;
+  float dmax = 0.0f;
+  // ---- output deltas (the fp32 kernel's arithmetic, operation for operation) -> fp32 tile, row maxima ---------------------
+  {
+    __shared__ double s_tot[2][kBhThreads / 64];
+    float ratio = 0.0f;
+    if (p.prob == 1) {
+      double tm = 0.0, tv = 0.0;
+      for (int w = tid; w < p.n_items; w += kBhThreads) {
+        tm += p.loss_part[(size_t)w * 3];
+        tv += p.loss_part[(size_t)w * 3 + 1];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        tm += __shfl_down(tm, o, 64);
+        tv += __shfl_down(tv, o, 64);
+      }
+      if (lane == 0) { s_tot[0][wave] = tm; s_tot[1][wave] = tv; }
+      __syncthreads();
+      tm = 0.0; tv = 0.0;
+      for (int w = 0; w < kBhThreads / 64; ++w) { tm += s_tot[0][w]; tv += s_tot[1][w]; }
+      ratio = (float)(0.05 * tm / tv);
+    } else {
+      __syncthreads();
+    }
+    const float inv_bd = 1.0f / ((float)p.B * (float)p.D);
+    for (int i = tid; i < kBhRows * p.OPk; i += kBhThreads) {
+      const int b = i / p.OPk, k = i - b * p.OPk;
+      float v = 0.0f;
+      const int row = row0 + b;
+      if (row < p.B) {
+        if (p.fuse) {
+          if (k < p.O) {
+            const float *orow = p.o + ((size_t)e * p.B + row) * p.O;
+            const int src = p.idx ? p.idx[(size_t)e * p.idx_stride + row] : row;
+            const int dd = (k < p.D) ? k : k - p.D;
+            float t = p.targets[(size_t)src * p.D + dd];
+            if (p.out_mu) t = (t - p.out_mu[dd]) / p.out_sig[dd];
+            const float diff = orow[dd] - t;
+            if (!p.prob) {
+              v = diff * inv_bd;
+            } else if (p.prob == 2) {
+              const float iv = expf(-orow[p.D + dd]);
+              v = (k < p.D) ? iv * diff * inv_bd : (0.5f - 0.5f * iv * diff * diff) * inv_bd;
+            } else if (k < p.D) {
+              v = 2.0f * diff * inv_bd;
+            } else {
+              const float lv = orow[k], var = expf(lv);
+              v = (2.0f * ratio * (var - diff * diff) * var + 0.1f * lv) * inv_bd;
+            }
+          }
+          p.d3_out[((size_t)e * p.B + row) * p.OPk + k] = v;
+        } else {
+          v = p.d3[((size_t)e * p.B + row) * p.OPk + k];
+        }
+      }
+      d3f[b * p.OPk + k] = v;
+      const float av = fabsf(v);
+      dmax = fmaxf(dmax, av);
+      if (av > 0.0f) atomicMax(&s_rowmax[b], __float_as_uint(av));     // (non-negative floats order like their bit patterns)
+    }
+  }
+  auto wave_max_to = [&](float m, float *slot) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) slot[wave] = m;
+  };
+  wave_max_to(dmax, s_dmax[0]);
+  dmax = 0.0f;
+  __syncthreads();
+  if (tid < kBhRows) {
+    const float m3 = __uint_as_float(s_rowmax[tid]);
+    const float t3 = pow2_lift(m3);
+    // |d2[row][n]| = |g2 sum_k d3[row][k] W2[n][k]| <= 1.1 OPk max |W2| max |d3[row]|   (swish' <= 1.0999)
+    const float t2 = pow2_lift(1.1f * (float)p.OPk * st[11] * m3);
+    r_t3[tid] = t3;
+    r_inv3[tid] = 1.0f / (st[8] * t3);
+    r_t2[tid] = t2;
+    r_inv2[tid] = 1.0f / (st[4] * t2);
+  }
+  __syncthreads();
+  {
+    const int KP = 16 * a.s3;
+    for (int i = tid; i < kBhRows * KP; i += kBhThreads) {
+      const int b = i / KP, k = i - b * KP;
+      const float v = k < p.OPk ? d3f[b * p.OPk + k] : 0.0f;
+      _Float16 q1, q2;
+      split_h(v * r_t3[b], q1, q2);
+      d3img[(size_t)b * D3S + k] = q1;
+      d3img[(size_t)kBhRows * D3S + (size_t)b * D3S + k] = q2;
+    }
+  }
+  // this lane's rows of the two row tiles, its export offsets
+  const bool valid[2] = {row0 + r < p.B, row0 + 32 + r < p.B};
+  const size_t grow[2] = {((size_t)e * p.B + row0 + r) * kBhHid, ((size_t)e * p.B + row0 + 32 + r) * kBhHid};
+  f32x4 gq[2][2][4];      // [n-tile of the wave][row tile][quad]
+  auto load_g = [&](const float *g) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = 32 * (2 * wave + t) + 8 * q + 4 * hh;
+          f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+          if (valid[bt]) v = *reinterpret_cast<const f32x4 *>(g + grow[bt] + n);
+          gq[t][bt][q] = v;
+        }
+  };
+  f32x16 acc[2][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][bt][i] = 0.0f;
+  };
+  auto read_b = [&](f16x8 (&x)[2], const _Float16 *img, int str, int bt, int sl) {
+    const _Float16 *q = img + (size_t)(32 * bt + r) * str + 16 * sl + 8 * hh;
+    x[0] = *reinterpret_cast<const f16x8 *>(q);
+    x[1] = *reinterpret_cast<const f16x8 *>(q + (size_t)kBhRows * str);
+  };
+  // ---- d2 = (d3 W2^T) * g2 -----------------------------------------------------------------------------------------------
+  load_g(p.g2);
+  zero_acc();
+  {
+    const f16x8 *w2 = a.w2t + (size_t)e * a.w2t_stride + lane;       // + ((tile * s3 + s) * 2 + piece) * 64
+    f16x8 A2[4][2][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f16x8 *q = w2 + ((size_t)((2 * wave + t) * a.s3 + (s < a.s3 ? s : 0)) * 2) * 64;
+        A2[s][t][0] = q[0]; A2[s][t][1] = q[64];
+      }
+    __syncthreads();           // the d3 image is complete
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (s < a.s3) {
+#pragma unroll
+        for (int bt = 0; bt < 2; ++bt) {
+          f16x8 bf[2];
+          read_b(bf, d3img, D3S, bt, s);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) mm3(acc[t][bt], A2[s][t][0], A2[s][t][1], bf[0], bf[1]);
+        }
+      }
+  }
+  // (every wave has read the fp32 tile that aliases the d2 image long ago: the barrier above)
+#pragma unroll
+  for (int bt = 0; bt < 2; ++bt) {
+    const float inv3 = r_inv3[32 * bt + r], t2 = r_t2[32 * bt + r];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = 32 * (2 * wave + t) + 8 * q + 4 * hh;
+        f32x4 v;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = (acc[t][bt][4 * q + s] * inv3) * gq[t][bt][q][s];
+        if (valid[bt]) {
+          *reinterpret_cast<f32x4 *>(p.d2 + grow[bt] + n) = v;
+          dmax = fmaxf(fmaxf(dmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+        unsigned q1[2], q2[2];
+        split2<false>(v[0], v[1], t2, q1[0], q2[0]);
+        split2<false>(v[2], v[3], t2, q1[1], q2[1]);
+        _Float16 *c1 = d2img + (size_t)(32 * bt + r) * kBhD2Str + n;
+        *reinterpret_cast<uint2 *>(c1) = make_uint2(q1[0], q1[1]);
+        *reinterpret_cast<uint2 *>(c1 + (size_t)kBhRows * kBhD2Str) = make_uint2(q2[0], q2[1]);
+      }
+  }
+  wave_max_to(dmax, s_dmax[1]);
+  dmax = 0.0f;
+  // ---- d1 = (d2 W1^T) * g1 -----------------------------------------------------------------------------------------------
+  load_g(p.g1);
+  zero_acc();
+  {
+    const f16x8 *w1 = a.w1t + (size_t)e * a.w1t_stride + lane;       // + ((tile * 32 + s) * 2 + piece) * 64
+    constexpr int S1 = kBhHid / 16, RING = 3;
+    f16x8 A1[RING][2][2];
+    auto load_a = [&](f16x8 (&x)[2][2], int s) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f16x8 *q = w1 + ((size_t)((2 * wave + t) * S1 + s) * 2) * 64;
+        x[t][0] = q[0]; x[t][1] = q[64];
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) load_a(A1[s], s);
+    __syncthreads();           // the d2 image is complete
+#pragma unroll
+    for (int s = 0; s < S1; ++s) {
+      if (s + RING - 1 < S1) load_a(A1[(s + RING - 1) % RING], s + RING - 1);
+#pragma unroll
+      for (int bt = 0; bt < 2; ++bt) {
+        f16x8 bf[2];
+        read_b(bf, d2img, kBhD2Str, bt, s);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) mm3(acc[t][bt], A1[s % RING][t][0], A1[s % RING][t][1], bf[0], bf[1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int bt = 0; bt < 2; ++bt) {
+    const float inv2 = r_inv2[32 * bt + r];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = 32 * (2 * wave + t) + 8 * q + 4 * hh;
+        f32x4 v;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = (acc[t][bt][4 * q + s] * inv2) * gq[t][bt][q][s];
+        if (valid[bt]) {
+          *reinterpret_cast<f32x4 *>(p.d1 + grow[bt] + n) = v;
+          dmax = fmaxf(fmaxf(dmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+      }
+  }
+  if (p.opmax) {
+    wave_max_to(dmax, s_dmax[2]);
+    __syncthreads();
+    if (tid < 3) {
+      const float *sm = s_dmax[2 - tid];      // slots 3, 4, 5 = d1, d2, d3
+      float m = 0.0f;
+      for (int w = 0; w < kBhThreads / 64; ++w) m = fmaxf(m, sm[w]);
+      // (the weight-gradient kernel reads the maxima per 32-row tile: this item covers two of them)
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int t32 = 2 * (int)blockIdx.x + h2;
+        if (t32 < a.tiles32) p.opmax[((size_t)e * a.tiles32 + t32) * 8 + 3 + tid] = m;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // weight gradients:  C[e][m][n] = sum_b A[e][b][m] * Bm[e][b][n]      (K of the GEMM = the batch)
 // Both operands are read straight from their [row][feature] arrays: a lane's 16-B (A) / 8-B (Bm) load of one
 // batch row feeds 4 / 2 MFMA tiles whose rows / columns are interleaved (tile mi holds m0 + 4 i + mi), so every
@@ -1173,6 +1452,8 @@ struct AdamWArgs {
   float *bwd; int b_kg; size_t b_stride;   // backward pack (nullptr for the first layer)
   float lr_t, b1, b2, eps;
   int apply;                               // 0: pack only (weights loaded from the host)
+  float *wmax_part;                        // [blocks] largest |w| of each block's 256 consecutive elements (nullptr: not wanted);
+                                           // a member's elements are a whole number of blocks: the f16 backward chain lifts W^T by it
 };
 
 __device__ __forceinline__ size_t pack_index(int k, int n, int kg) {
@@ -1182,24 +1463,55 @@ __device__ __forceinline__ size_t pack_index(int k, int n, int kg) {
 __device__ __forceinline__ void adam_w(const AdamWArgs &p, unsigned block) {
   const size_t per = (size_t)p.K * p.N;
   const size_t i = (size_t)block * kThreads + threadIdx.x;
-  if (i >= per * p.E) return;
-  const int e = (int)(i / per);
-  const size_t r = i - (size_t)e * per;
-  const int k = (int)(r / p.N), n = (int)(r - (size_t)k * p.N);
-  float w = p.W[i];
-  if (p.apply) {
-    float g = 0.0f;
+  float w = 0.0f;
+  if (i < per * p.E) {
+    const int e = (int)(i / per);
+    const size_t r = i - (size_t)e * per;
+    const int k = (int)(r / p.N), n = (int)(r - (size_t)k * p.N);
+    w = p.W[i];
+    if (p.apply) {
+      float g = 0.0f;
 #pragma unroll 8
-    for (int s = 0; s < p.n_parts; ++s) g += p.parts[(size_t)s * p.part_stride + i];   // fixed order: reproducible
-    g += p.decay * w;                      // d/dw of decay * l2_loss(w), models/pens/fc.py:167-168
-    float m = p.m[i], v = p.v[i];
-    m += (g - m) * (1.0f - p.b1);
-    v += (g * g - v) * (1.0f - p.b2);
-    w -= p.lr_t * m / (sqrtf(v) + p.eps);
-    p.m[i] = m; p.v[i] = v; p.W[i] = w;
+      for (int s = 0; s < p.n_parts; ++s) g += p.parts[(size_t)s * p.part_stride + i];   // fixed order: reproducible
+      g += p.decay * w;                      // d/dw of decay * l2_loss(w), models/pens/fc.py:167-168
+      float m = p.m[i], v = p.v[i];
+      m += (g - m) * (1.0f - p.b1);
+      v += (g * g - v) * (1.0f - p.b2);
+      w -= p.lr_t * m / (sqrtf(v) + p.eps);
+      p.m[i] = m; p.v[i] = v; p.W[i] = w;
+    }
+    p.fwd[(size_t)e * p.f_stride + pack_index(k, n, p.f_kg)] = w;
+    if (p.bwd) p.bwd[(size_t)e * p.b_stride + pack_index(n, k, p.b_kg)] = w;
   }
-  p.fwd[(size_t)e * p.f_stride + pack_index(k, n, p.f_kg)] = w;
-  if (p.bwd) p.bwd[(size_t)e * p.b_stride + pack_index(n, k, p.b_kg)] = w;
+  if (p.wmax_part) {      // (uniform per tensor)
+    __shared__ float s_wm[kThreads / 64];
+    float m = fabsf(w);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) s_wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) p.wmax_part[block] = fmaxf(fmaxf(s_wm[0], s_wm[1]), fmaxf(s_wm[2], s_wm[3]));
+  }
+}
+
+// the members' lifts for the f16 backward chain from the blocks' maxima: stats[e][4 l] = 2^k with max |W_l| 2^k in [2^13, 2^14),
+// stats[e][4 l + 3] = max |W_l| (the slots h3_stats_kernel fills for the forward images); grid (E, 2): l = 1, 2
+__global__ __launch_bounds__(kThreads) void wmax_fold_kernel(const float *part1, int blocks1, const float *part2, int blocks2, float *stats) {
+  const int e = blockIdx.x, l = 1 + blockIdx.y;
+  const float *part = (l == 1 ? part1 + (size_t)e * blocks1 : part2 + (size_t)e * blocks2);
+  const int nb = l == 1 ? blocks1 : blocks2;
+  float m = 0.0f;
+  for (int i = threadIdx.x; i < nb; i += kThreads) m = fmaxf(m, part[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __shared__ float s_m[kThreads / 64];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    stats[(size_t)e * NSTAT + 4 * l] = pow2_lift(m);
+    stats[(size_t)e * NSTAT + 4 * l + 3] = m;
+  }
 }
 
 struct AdamBArgs {
@@ -1270,6 +1582,12 @@ struct cmbpo_trainer {
   double *loss_part;             // [E * ceil(max_batch / 32)][3] per-tile loss statistics of the training forward
   size_t wsize[3], bsize[3];
   float *opmax;                  // [E][ceil(max_batch / 32)][kOpMax] per-tile largest |x|, |h1|, |h2|, |d1|, |d2|, |d3| of the step
+  // the backward chain on the f16 path (bwd_chain_h_kernel; 512-wide, at most 64 padded outputs): two-piece images of W1^T and
+  // W2^T and the members' weight statistics, rebuilt from the packs at every step (the packs change with every Adam step)
+  void *b16 = nullptr;           // one allocation: W1^T image | W2^T image | stats | block maxima of |W1|, |W2| (Adam leaves them)
+  size_t b16_w2t_off = 0, b16_stats_off = 0;   // 16-byte units
+  int b16_s3 = 0;
+  int b16_blocks[2] = {0, 0};    // 256-element blocks per member of W1, W2
 };
 
 namespace {
@@ -1387,6 +1705,43 @@ int launch_bwd(const BwdArgs &a, int tiles, int E, size_t lds, hipStream_t s) {
   return CMBPO_OK;
 }
 
+// 0 / 1: the backward chain as fp32 MFMAs / on the f16 path where the shape allows (CMBPO_TRAIN_BWD_F16=0 turns it off)
+bool bwd_f16() {
+  static const bool on = !(getenv("CMBPO_TRAIN_BWD_F16") && getenv("CMBPO_TRAIN_BWD_F16")[0] == '0');
+  return on && train_f16();
+}
+
+int launch_bwd_h(cmbpo_trainer *t, const BwdArgs &b, int batch, hipStream_t s) {
+  const int E = t->E, H = t->H;
+  f16x8 *base = reinterpret_cast<f16x8 *>(t->b16);
+  float *stats = reinterpret_cast<float *>(base + t->b16_stats_off);
+  const size_t w1t_stride = (size_t)(H / 32) * (H / 16) * 2 * 64, w2t_stride = (size_t)(H / 32) * t->b16_s3 * 2 * 64;
+  // the members' lifts from the block maxima the last Adam step (or weight load) left: one small launch instead of a pass
+  // over the packs (h3_stats_kernel: 24 us)
+  float *wm1 = stats + (size_t)E * NSTAT, *wm2 = wm1 + (size_t)E * t->b16_blocks[0];
+  hipLaunchKernelGGL(wmax_fold_kernel, dim3(E, 2), dim3(kThreads), 0, s, wm1, t->b16_blocks[0], wm2, t->b16_blocks[1], stats);
+  cmbpo_internal_f16_pack_from(t->wpb1, (size_t)(H / 32) * (H / 8) * 256, H / 8, H / 32, base, w1t_stride, H / 32, H / 16, E, stats, 1, s);
+  cmbpo_internal_f16_pack_from(t->wpb2, (size_t)(H / 32) * (t->OPk / 8) * 256, t->OPk / 8, H / 32, base + t->b16_w2t_off, w2t_stride,
+                               H / 32, t->b16_s3, E, stats, 2, s);
+  BwdHArgs a{};
+  a.b = b;
+  a.w1t = base; a.w2t = base + t->b16_w2t_off;
+  a.w1t_stride = w1t_stride; a.w2t_stride = w2t_stride;
+  a.stats = stats;
+  a.s3 = t->b16_s3;
+  a.tiles32 = cmbpo_ceil_div(batch, 32);
+  const size_t lds = bh_lds_bytes(t->b16_s3);
+  static size_t attr_bytes = 0;
+  if (lds > attr_bytes) {
+    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_chain_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+    attr_bytes = lds;
+  }
+  hipLaunchKernelGGL(bwd_chain_h_kernel, dim3(cmbpo_ceil_div(batch, kBhRows), E), dim3(kBhThreads), lds, s, a);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
 // masters -> packs (apply == 0) or one Adam step (apply == 1)
 int launch_update(cmbpo_trainer *t, int apply, float lr_t, hipStream_t s) {
   cmbpo_mlp *m = t->m;
@@ -1413,6 +1768,11 @@ int launch_update(cmbpo_trainer *t, int apply, float lr_t, hipStream_t s) {
     a.fwd = fwd[l]; a.f_kg = f_kg[l]; a.f_stride = f_stride[l];
     a.bwd = bwd[l]; a.b_kg = b_kg[l]; a.b_stride = b_stride[l];
     a.lr_t = lr_t; a.b1 = t->b1; a.b2 = t->b2; a.eps = t->eps; a.apply = apply;
+    a.wmax_part = nullptr;
+    if (t->b16 && l >= 1) {
+      float *wm = reinterpret_cast<float *>(reinterpret_cast<f16x8 *>(t->b16) + t->b16_stats_off) + (size_t)E * NSTAT;
+      a.wmax_part = l == 1 ? wm : wm + (size_t)E * t->b16_blocks[0];
+    }
     all.first[l] = blocks;
     blocks += (unsigned)((t->wsize[l] + kThreads - 1) / kThreads);
   }
@@ -1593,6 +1953,22 @@ extern "C" int cmbpo_trainer_create(cmbpo_trainer_t **out, cmbpo_mlp_t *m, int m
   t->sums = reinterpret_cast<double *>(P + osums);
   t->loss_part = reinterpret_cast<double *>(P + olp);
   t->opmax = P + oom;
+  if (H == 512 && !t->fused && t->OPk <= 64) {
+    // images for the f16 backward chain (bwd_chain_h_kernel); without them the fp32 kernel runs
+    t->b16_s3 = cmbpo_ceil_div(t->OPk, 16);
+    const size_t w1t = (size_t)E * (H / 32) * (H / 16) * 2 * 64, w2t = (size_t)E * (H / 32) * t->b16_s3 * 2 * 64;
+    t->b16_w2t_off = w1t;
+    t->b16_stats_off = w1t + w2t;
+    t->b16_blocks[0] = (int)((size_t)H * H / kThreads);
+    t->b16_blocks[1] = (int)((size_t)H * t->O / kThreads);
+    const size_t tail_floats = (size_t)E * NSTAT + (size_t)E * (t->b16_blocks[0] + t->b16_blocks[1]);
+    if (hipMalloc(&t->b16, (w1t + w2t) * 16 + tail_floats * sizeof(float)) != hipSuccess) {
+      (void)hipGetLastError();
+      t->b16 = nullptr;
+    } else {
+      (void)hipMemset(reinterpret_cast<char *>(t->b16) + (w1t + w2t) * 16, 0, tail_floats * sizeof(float));
+    }
+  }
   *out = t;
   return CMBPO_OK;
 }
@@ -1600,6 +1976,7 @@ extern "C" int cmbpo_trainer_create(cmbpo_trainer_t **out, cmbpo_mlp_t *m, int m
 extern "C" void cmbpo_trainer_destroy(cmbpo_trainer_t *t) {
   if (!t) return;
   if (t->pool) (void)hipFree(t->pool);
+  if (t->b16) (void)hipFree(t->b16);
   delete t;
 }
 
@@ -1757,7 +2134,8 @@ extern "C" int cmbpo_trainer_step(cmbpo_trainer_t *t, const float *d_inputs, int
   }
   const size_t lds = ((size_t)H / 4 * 32 + (size_t)t->OPk / 4 * 32) * sizeof(f32x4);
   const int tiles = cmbpo_ceil_div(batch, 32);
-  rc = (H == 512) ? launch_bwd<512>(b, tiles, E, lds, s) : (H == 256 ? launch_bwd<256>(b, tiles, E, lds, s) : launch_bwd<128>(b, tiles, E, lds, s));
+  if (t->b16 && bwd_f16()) rc = launch_bwd_h(t, b, batch, s);
+  else rc = (H == 512) ? launch_bwd<512>(b, tiles, E, lds, s) : (H == 256 ? launch_bwd<256>(b, tiles, E, lds, s) : launch_bwd<128>(b, tiles, E, lds, s));
   if (rc != CMBPO_OK) return rc;
 
   if (H == 512) {

@@ -557,6 +557,312 @@ __global__ __launch_bounds__(kBhThreads) void bwd_chain_h_kernel(const BwdHArgs 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The training forward of a 512-wide probabilistic ensemble on the same path (what ens_mlp_kernel<512, 1, swish,
+// HEAD_TRAIN> computes: per-member bootstrap rows, raw outputs, the scaled inputs, h = swish(z) and g = swish'(z) of both
+// layers as [member][row][feature] arrays, the tile's loss statistics and largest operand magnitudes).  An item is 64 rows
+// of one member on 8 waves.  x, h1 and h2 pass through LDS as two-piece f16 images, every row lifted by its own largest
+// magnitude: the activations of a layer stay in the accumulator registers between the pass that exports them and takes
+// the row maxima (LDS atomics on the float bits) and the pass, a barrier later, that splits them under the exact lift.
+// Wave w owns hidden n-tiles 2 w, 2 w + 1 x both row tiles; the 64-wide output layer runs on waves 0-3 (one (output tile,
+// row tile) pair each, the whole K): 96 of an item's 3 744 MFMAs per SIMD.
+// ------------------------------------------------------------------------------------------------------------
+struct FwdHArgs {
+  const float *inputs;              // [N][I]
+  const int32_t *idx; int idx_stride;     // [E][idx_stride] rows of `inputs` / `targets` (nullptr: row b)
+  int n_rows, I, IP, s0;            // batch rows, input width, padded width, k-slabs of the input layer (IP <= 16 s0)
+  const float *in_mu, *in_sig;      // input scaler or nullptr
+  const f16x8 *w0, *w1, *w2;        // images [member][n-tile][k-slab][piece][lane]; w2: 2 n-tiles, plain k order
+  size_t w0_stride, w1_stride, w2_stride;
+  const float *b0, *b1, *b2; int b2_ld;   // [E][512], [E][512], [E][b2_ld]
+  const float *stats;               // [E][NSTAT]: the weights' lifts at [0], [4], [8]
+  int O, D;                         // raw outputs per row (<= 64), target dims
+  float *x, *h1, *g1, *h2, *g2;     // exports (nullptr: none)
+  float *o;                         // [E][n_rows][O]
+  const float *targets, *out_mu, *out_sig;
+  double *loss_part;                // [E * tiles32][3] or nullptr
+  float *opmax;                     // [E * tiles32][8] slots 0..2 or nullptr
+  int tiles32;
+};
+
+constexpr int kFhXStr = 16 * 4 + 8;       // halves per row of the x image (up to four input slabs)
+constexpr int kFhOStr = 65;               // floats per row of the output tile
+__host__ __device__ constexpr size_t fh_lds_bytes() {
+  return (size_t)2 * kBhRows * kBhD2Str * 2 + (size_t)2 * kBhRows * kFhXStr * 2 + (size_t)(2 * kBhHid + 64) * 4;
+}
+static_assert((size_t)kBhRows * kFhOStr * 4 <= (size_t)2 * kBhRows * kFhXStr * 2, "the output tile aliases the x image");
+
+__global__ __launch_bounds__(kBhThreads) void fwd_train_h_kernel(const FwdHArgs a) {
+  extern __shared__ f32x4 smem[];
+  _Float16 *himg = reinterpret_cast<_Float16 *>(smem);                          // [2 pieces][64][kBhD2Str]: h1, then h2
+  _Float16 *ximg = himg + (size_t)2 * kBhRows * kBhD2Str;                       // [2 pieces][64][kFhXStr]
+  float *otile = reinterpret_cast<float *>(ximg);                               // [64][kFhOStr] (aliases the x image: dead by then)
+  float *bias0 = reinterpret_cast<float *>(ximg + (size_t)2 * kBhRows * kFhXStr), *bias1 = bias0 + kBhHid, *bias2 = bias1 + kBhHid;
+  __shared__ int s_rows[kBhRows];
+  __shared__ float s_inv0[kBhRows];
+  __shared__ unsigned s_hmax[2][kBhRows];
+  __shared__ float s_opmax[3][kBhThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int e = blockIdx.y, row0 = blockIdx.x * kBhRows;
+  const float *st = a.stats + (size_t)e * NSTAT;
+  if (tid < kBhRows) {
+    const int row = row0 + tid;
+    s_rows[tid] = row < a.n_rows ? (a.idx ? a.idx[(size_t)e * a.idx_stride + row] : row) : -1;
+    s_hmax[0][tid] = 0u; s_hmax[1][tid] = 0u;
+  }
+  bias0[tid] = a.b0[(size_t)e * kBhHid + tid];
+  bias1[tid] = a.b1[(size_t)e * kBhHid + tid];
+  if (tid < 64) bias2[tid] = tid < a.O ? a.b2[(size_t)e * a.b2_ld + tid] : 0.0f;
+  __syncthreads();
+  // ---- the scaled input rows: export, the row's lift, the two-piece image (eight threads per row) -----------------------
+  float xmax_t = 0.0f;
+  {
+    const int b = tid >> 3, c = tid & 7;
+    const int src = s_rows[b];
+    float xs[8];
+    float m = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = c + 8 * u;
+      float x = 0.0f;
+      if (k < a.I && src >= 0) {
+        x = a.inputs[(size_t)src * a.I + k];
+        if (a.in_mu) x = (x - a.in_mu[k]) / a.in_sig[k];       // TensorStandardScaler.transform, models/pens/utils.py:156
+      }
+      xs[u] = x;
+      m = fmaxf(m, fabsf(x));
+      if (a.x && src >= 0 && k < a.IP) a.x[((size_t)e * a.n_rows + row0 + b) * a.IP + k] = x;
+    }
+    xmax_t = m;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const float t0 = pow2_lift(m);
+    if (c == 0) s_inv0[b] = 1.0f / (st[0] * t0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = c + 8 * u;
+      if (k < 16 * a.s0) {
+        _Float16 q1, q2;
+        split_h(xs[u] * t0, q1, q2);
+        ximg[(size_t)b * kFhXStr + k] = q1;
+        ximg[(size_t)kBhRows * kFhXStr + (size_t)b * kFhXStr + k] = q2;
+      }
+    }
+  }
+  auto wave_max_to = [&](float m, float *slot) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) slot[wave] = m;
+  };
+  wave_max_to(xmax_t, s_opmax[0]);
+  const bool valid[2] = {row0 + r < a.n_rows, row0 + 32 + r < a.n_rows};
+  const size_t grow[2] = {((size_t)e * a.n_rows + row0 + r) * kBhHid, ((size_t)e * a.n_rows + row0 + 32 + r) * kBhHid};
+  f32x16 acc[2][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][bt][i] = 0.0f;
+  };
+  auto read_b = [&](f16x8 (&x)[2], const _Float16 *img, int str, int bt, int sl) {
+    const _Float16 *q = img + (size_t)(32 * bt + r) * str + 16 * sl + 8 * hh;
+    x[0] = *reinterpret_cast<const f16x8 *>(q);
+    x[1] = *reinterpret_cast<const f16x8 *>(q + (size_t)kBhRows * str);
+  };
+  // z -> h = swish(z), g = swish'(z) (swish_with_grad of the fp32 kernel); exports; the rows' largest |h| (pass 1), then, a
+  // barrier later, the two-piece image of h under the rows' exact lifts (pass 2).  Returns the lifts' inverses 1 / (s t).
+  auto activate_export = [&](const float *bias, const float (&inv)[2], float *eh, float *eg, unsigned *rowmax, float *opslot) {
+    float hmax_t = 0.0f;
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt) {
+      float hm = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = 32 * (2 * wave + t) + 8 * q + 4 * hh;
+          const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + n);
+          f32x4 hv, gv;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float z = __builtin_fmaf(acc[t][bt][4 * q + s], inv[bt], bv[s]);
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+            hv[s] = z * sg;
+            gv[s] = sg * (1.0f + z * (1.0f - sg));
+            acc[t][bt][4 * q + s] = hv[s];
+            hm = fmaxf(hm, fabsf(hv[s]));
+          }
+          if (eh && valid[bt]) {
+            *reinterpret_cast<f32x4 *>(eh + grow[bt] + n) = hv;
+            *reinterpret_cast<f32x4 *>(eg + grow[bt] + n) = gv;
+          }
+        }
+      if (hm > 0.0f) atomicMax(&rowmax[32 * bt + r], __float_as_uint(hm));
+      if (valid[bt]) hmax_t = fmaxf(hmax_t, hm);
+    }
+    wave_max_to(hmax_t, opslot);
+  };
+  auto split_image = [&](const unsigned *rowmax, float s_w, float (&inv_next)[2]) {
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt) {
+      const float tl = pow2_lift(__uint_as_float(rowmax[32 * bt + r]));
+      inv_next[bt] = 1.0f / (s_w * tl);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = 32 * (2 * wave + t) + 8 * q + 4 * hh;
+          unsigned q1[2], q2[2];
+          split2<false>(acc[t][bt][4 * q], acc[t][bt][4 * q + 1], tl, q1[0], q2[0]);
+          split2<false>(acc[t][bt][4 * q + 2], acc[t][bt][4 * q + 3], tl, q1[1], q2[1]);
+          _Float16 *c1 = himg + (size_t)(32 * bt + r) * kBhD2Str + n;
+          *reinterpret_cast<uint2 *>(c1) = make_uint2(q1[0], q1[1]);
+          *reinterpret_cast<uint2 *>(c1 + (size_t)kBhRows * kBhD2Str) = make_uint2(q2[0], q2[1]);
+        }
+    }
+  };
+  // ---- layer 0 -----------------------------------------------------------------------------------------------------------
+  zero_acc();
+  {
+    const f16x8 *w0 = a.w0 + (size_t)e * a.w0_stride + lane;       // + ((tile * s0 + s) * 2 + piece) * 64
+    f16x8 A0[4][2][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f16x8 *q = w0 + ((size_t)((2 * wave + t) * a.s0 + (s < a.s0 ? s : 0)) * 2) * 64;
+        A0[s][t][0] = q[0]; A0[s][t][1] = q[64];
+      }
+    __syncthreads();           // the x image and the rows' lifts are complete
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (s < a.s0) {
+#pragma unroll
+        for (int bt = 0; bt < 2; ++bt) {
+          f16x8 bf[2];
+          read_b(bf, ximg, kFhXStr, bt, s);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) mm3(acc[t][bt], A0[s][t][0], A0[s][t][1], bf[0], bf[1]);
+        }
+      }
+  }
+  float inv[2] = {s_inv0[r], s_inv0[32 + r]};
+  activate_export(bias0, inv, a.h1, a.g1, s_hmax[0], s_opmax[1]);
+  __syncthreads();             // the rows' largest |h1| are complete
+  split_image(s_hmax[0], st[4], inv);
+  // ---- layer 1 -----------------------------------------------------------------------------------------------------------
+  zero_acc();
+  {
+    const f16x8 *w1 = a.w1 + (size_t)e * a.w1_stride + lane;       // + ((tile * 32 + s) * 2 + piece) * 64
+    constexpr int S1 = kBhHid / 16, RING = 3;
+    f16x8 A1[RING][2][2];
+    auto load_a = [&](f16x8 (&x)[2][2], int s) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f16x8 *q = w1 + ((size_t)((2 * wave + t) * S1 + s) * 2) * 64;
+        x[t][0] = q[0]; x[t][1] = q[64];
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) load_a(A1[s], s);
+    __syncthreads();           // the h1 image is complete
+#pragma unroll
+    for (int s = 0; s < S1; ++s) {
+      if (s + RING - 1 < S1) load_a(A1[(s + RING - 1) % RING], s + RING - 1);
+#pragma unroll
+      for (int bt = 0; bt < 2; ++bt) {
+        f16x8 bf[2];
+        read_b(bf, himg, kBhD2Str, bt, s);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) mm3(acc[t][bt], A1[s % RING][t][0], A1[s % RING][t][1], bf[0], bf[1]);
+      }
+    }
+  }
+  activate_export(bias1, inv, a.h2, a.g2, s_hmax[1], s_opmax[2]);
+  __syncthreads();             // the rows' largest |h2| are complete, and every wave has read the h1 image
+  split_image(s_hmax[1], st[8], inv);
+  __syncthreads();             // the h2 image is complete
+  // ---- output layer: waves 0-3, one (output tile, row tile) pair each ---------------------------------------------------
+  if (wave < 4) {
+    const int tt = wave & 1, bt = wave >> 1;
+    const f16x8 *w2 = a.w2 + (size_t)e * a.w2_stride + lane + (size_t)tt * 32 * 2 * 64;    // + (s * 2 + piece) * 64
+    f32x16 o;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = 0.0f;
+    constexpr int S1 = kBhHid / 16;
+    f16x8 A2[2][2];
+    A2[0][0] = w2[0]; A2[0][1] = w2[64];
+#pragma unroll 4
+    for (int s = 0; s < S1; ++s) {
+      const int sn = s + 1 < S1 ? s + 1 : s;
+      A2[(s + 1) & 1][0] = w2[(size_t)sn * 128]; A2[(s + 1) & 1][1] = w2[(size_t)sn * 128 + 64];
+      f16x8 bf[2];
+      read_b(bf, himg, kBhD2Str, bt, s);
+      mm3(o, A2[s & 1][0], A2[s & 1][1], bf[0], bf[1]);
+    }
+    const float inv2 = inv[bt];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = 32 * tt + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      otile[(32 * bt + r) * kFhOStr + n] = __builtin_fmaf(o[i], inv2, bias2[n]);
+    }
+  }
+  __syncthreads();
+  // ---- raw outputs, the tile's loss statistics and operand maxima (as the fp32 kernel) -------------------------------------
+  for (int i = tid; i < kBhRows * a.O; i += kBhThreads) {
+    const int b = i / a.O, n = i - b * a.O;
+    if (s_rows[b] >= 0) a.o[((size_t)e * a.n_rows + row0 + b) * a.O + n] = otile[b * kFhOStr + n];
+  }
+  const size_t item0 = (size_t)e * a.tiles32 + 2 * blockIdx.x;
+  const bool second = 2 * (int)blockIdx.x + 1 < a.tiles32;
+  if (a.opmax && tid < 3) {
+    const float *sm = s_opmax[tid];
+    float m = 0.0f;
+    for (int w = 0; w < kBhThreads / 64; ++w) m = fmaxf(m, sm[w]);
+    a.opmax[item0 * 8 + tid] = m;
+    if (second) a.opmax[(item0 + 1) * 8 + tid] = m;
+  }
+  if (a.loss_part) {
+    const int D = a.D;
+    const bool prob = a.O == 2 * D;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int i = tid; i < kBhRows * D; i += kBhThreads) {
+      const int b = i / D, d = i - b * D;
+      const int src = s_rows[b];
+      if (src < 0) continue;
+      float t = a.targets[(size_t)src * D + d];
+      if (a.out_mu) t = (t - a.out_mu[d]) / a.out_sig[d];
+      const float diff = otile[b * kFhOStr + d] - t;
+      const float mse = diff * diff;
+      s0 += (double)mse;
+      if (prob) {
+        const float lv = otile[b * kFhOStr + D + d];
+        const float dv = expf(lv) - mse;
+        s1 += (double)(dv * dv);
+        s2 += (double)(lv * lv);
+      }
+    }
+    __shared__ double s_loss[3][kBhThreads / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s0 += __shfl_down(s0, o, 64);
+      s1 += __shfl_down(s1, o, 64);
+      s2 += __shfl_down(s2, o, 64);
+    }
+    if (lane == 0) { s_loss[0][wave] = s0; s_loss[1][wave] = s1; s_loss[2][wave] = s2; }
+    __syncthreads();
+    if (tid < 3) {
+      double tsum = 0.0;
+      for (int w = 0; w < kBhThreads / 64; ++w) tsum += s_loss[tid][w];
+      a.loss_part[item0 * 3 + tid] = tsum;                 // (the backward kernel adds the entries of all 32-row tiles:
+      if (second) a.loss_part[(item0 + 1) * 3 + tid] = 0.0;   //  this item's sums stand in the first of its two)
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // weight gradients:  C[e][m][n] = sum_b A[e][b][m] * Bm[e][b][n]      (K of the GEMM = the batch)
 // Both operands are read straight from their [row][feature] arrays: a lane's 16-B (A) / 8-B (Bm) load of one
 // batch row feeds 4 / 2 MFMA tiles whose rows / columns are interleaved (tile mi holds m0 + 4 i + mi), so every
@@ -1495,11 +1801,12 @@ __device__ __forceinline__ void adam_w(const AdamWArgs &p, unsigned block) {
 }
 
 // the members' lifts for the f16 backward chain from the blocks' maxima: stats[e][4 l] = 2^k with max |W_l| 2^k in [2^13, 2^14),
-// stats[e][4 l + 3] = max |W_l| (the slots h3_stats_kernel fills for the forward images); grid (E, 2): l = 1, 2
-__global__ __launch_bounds__(kThreads) void wmax_fold_kernel(const float *part1, int blocks1, const float *part2, int blocks2, float *stats) {
-  const int e = blockIdx.x, l = 1 + blockIdx.y;
-  const float *part = (l == 1 ? part1 + (size_t)e * blocks1 : part2 + (size_t)e * blocks2);
-  const int nb = l == 1 ? blocks1 : blocks2;
+// stats[e][4 l + 3] = max |W_l| (the slots h3_stats_kernel fills for the forward images); grid (E, 3)
+__global__ __launch_bounds__(kThreads) void wmax_fold_kernel(const float *part0, int blocks0, const float *part1, int blocks1,
+                                                             const float *part2, int blocks2, float *stats) {
+  const int e = blockIdx.x, l = blockIdx.y;
+  const float *part = l == 0 ? part0 + (size_t)e * blocks0 : (l == 1 ? part1 + (size_t)e * blocks1 : part2 + (size_t)e * blocks2);
+  const int nb = l == 0 ? blocks0 : (l == 1 ? blocks1 : blocks2);
   float m = 0.0f;
   for (int i = threadIdx.x; i < nb; i += kThreads) m = fmaxf(m, part[i]);
 #pragma unroll
@@ -1584,10 +1891,12 @@ struct cmbpo_trainer {
   float *opmax;                  // [E][ceil(max_batch / 32)][kOpMax] per-tile largest |x|, |h1|, |h2|, |d1|, |d2|, |d3| of the step
   // the backward chain on the f16 path (bwd_chain_h_kernel; 512-wide, at most 64 padded outputs): two-piece images of W1^T and
   // W2^T and the members' weight statistics, rebuilt from the packs at every step (the packs change with every Adam step)
-  void *b16 = nullptr;           // one allocation: W1^T image | W2^T image | stats | block maxima of |W1|, |W2| (Adam leaves them)
-  size_t b16_w2t_off = 0, b16_stats_off = 0;   // 16-byte units
-  int b16_s3 = 0;
-  int b16_blocks[2] = {0, 0};    // 256-element blocks per member of W1, W2
+  void *b16 = nullptr;           // one allocation: W1^T | W2^T | W0 | W1 | W2 images | stats | block maxima of |W0|, |W1|, |W2|
+  size_t b16_w2t_off = 0, b16_f_off[3] = {0, 0, 0}, b16_stats_off = 0;   // 16-byte units
+  int b16_s3 = 0, b16_s0 = 0;    // k-slabs of the backward chain's first product / of the input layer
+  int b16_blocks[3] = {0, 0, 0}; // 256-element blocks per member of W0, W1, W2 (Adam leaves each block's largest |w|)
+  bool b16_fwd = false;          // the training forward runs on the f16 path too (probabilistic head, <= 64 inputs / outputs)
+  unsigned long b16_version = ~0ul;   // pack version the images were built from
 };
 
 namespace {
@@ -1711,23 +2020,45 @@ bool bwd_f16() {
   return on && train_f16();
 }
 
-int launch_bwd_h(cmbpo_trainer *t, const BwdArgs &b, int batch, hipStream_t s) {
+// the images of the f16 training kernels from the current packs: the members' lifts from the block maxima the last Adam step
+// (or weight load) left -- one small launch instead of a pass over the packs (h3_stats_kernel: 24 us) -- then one pack launch
+// per image
+int prepare_f16(cmbpo_trainer *t, hipStream_t s) {
+  cmbpo_mlp *m = t->m;
+  if (t->b16_version == m->pack_version) return CMBPO_OK;
   const int E = t->E, H = t->H;
   f16x8 *base = reinterpret_cast<f16x8 *>(t->b16);
   float *stats = reinterpret_cast<float *>(base + t->b16_stats_off);
+  float *wm0 = stats + (size_t)E * NSTAT, *wm1 = wm0 + (size_t)E * t->b16_blocks[0], *wm2 = wm1 + (size_t)E * t->b16_blocks[1];
+  hipLaunchKernelGGL(wmax_fold_kernel, dim3(E, 3), dim3(kThreads), 0, s, wm0, t->b16_blocks[0], wm1, t->b16_blocks[1], wm2,
+                     t->b16_blocks[2], stats);
   const size_t w1t_stride = (size_t)(H / 32) * (H / 16) * 2 * 64, w2t_stride = (size_t)(H / 32) * t->b16_s3 * 2 * 64;
-  // the members' lifts from the block maxima the last Adam step (or weight load) left: one small launch instead of a pass
-  // over the packs (h3_stats_kernel: 24 us)
-  float *wm1 = stats + (size_t)E * NSTAT, *wm2 = wm1 + (size_t)E * t->b16_blocks[0];
-  hipLaunchKernelGGL(wmax_fold_kernel, dim3(E, 2), dim3(kThreads), 0, s, wm1, t->b16_blocks[0], wm2, t->b16_blocks[1], stats);
   cmbpo_internal_f16_pack_from(t->wpb1, (size_t)(H / 32) * (H / 8) * 256, H / 8, H / 32, base, w1t_stride, H / 32, H / 16, E, stats, 1, s);
   cmbpo_internal_f16_pack_from(t->wpb2, (size_t)(H / 32) * (t->OPk / 8) * 256, t->OPk / 8, H / 32, base + t->b16_w2t_off, w2t_stride,
                                H / 32, t->b16_s3, E, stats, 2, s);
+  if (t->b16_fwd) {
+    const float *blob = m->d_blob;
+    cmbpo_internal_f16_pack_from(blob + m->off_wp0, (size_t)(H / 32) * (t->IP / 8) * 256, t->IP / 8, H / 32, base + t->b16_f_off[0],
+                                 (size_t)(H / 32) * t->b16_s0 * 2 * 64, H / 32, t->b16_s0, E, stats, 0, s);
+    cmbpo_internal_f16_pack_from(blob + m->off_wp1, (size_t)(H / 32) * (H / 8) * 256, H / 8, H / 32, base + t->b16_f_off[1], w1t_stride,
+                                 H / 32, H / 16, E, stats, 1, s);
+    cmbpo_internal_f16_pack_from(blob + m->off_wp2, (size_t)m->o_tiles * (H / 8) * 256, H / 8, m->o_tiles, base + t->b16_f_off[2],
+                                 (size_t)2 * (H / 16) * 2 * 64, 2, H / 16, E, stats, 2, s);
+  }
+  CMBPO_HIP_CHECK(hipGetLastError());
+  t->b16_version = m->pack_version;
+  return CMBPO_OK;
+}
+
+int launch_bwd_h(cmbpo_trainer *t, const BwdArgs &b, int batch, hipStream_t s) {
+  const int E = t->E, H = t->H;
+  if (int rc = prepare_f16(t, s)) return rc;
+  f16x8 *base = reinterpret_cast<f16x8 *>(t->b16);
   BwdHArgs a{};
   a.b = b;
   a.w1t = base; a.w2t = base + t->b16_w2t_off;
-  a.w1t_stride = w1t_stride; a.w2t_stride = w2t_stride;
-  a.stats = stats;
+  a.w1t_stride = (size_t)(H / 32) * (H / 16) * 2 * 64; a.w2t_stride = (size_t)(H / 32) * t->b16_s3 * 2 * 64;
+  a.stats = reinterpret_cast<const float *>(base + t->b16_stats_off);
   a.s3 = t->b16_s3;
   a.tiles32 = cmbpo_ceil_div(batch, 32);
   const size_t lds = bh_lds_bytes(t->b16_s3);
@@ -1738,6 +2069,43 @@ int launch_bwd_h(cmbpo_trainer *t, const BwdArgs &b, int batch, hipStream_t s) {
     attr_bytes = lds;
   }
   hipLaunchKernelGGL(bwd_chain_h_kernel, dim3(cmbpo_ceil_div(batch, kBhRows), E), dim3(kBhThreads), lds, s, a);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+// the training forward on the f16 path (fwd_train_h_kernel); arguments as run_forward
+int launch_fwd_h(cmbpo_trainer *t, const float *d_inputs, const int32_t *d_idx, int idx_stride, int rows, bool exports, hipStream_t s,
+                 const float *d_targets) {
+  cmbpo_mlp *m = t->m;
+  const int H = t->H;
+  if (int rc = prepare_f16(t, s)) return rc;
+  f16x8 *base = reinterpret_cast<f16x8 *>(t->b16);
+  FwdHArgs a{};
+  a.inputs = d_inputs; a.idx = d_idx; a.idx_stride = idx_stride;
+  a.n_rows = rows; a.I = t->I; a.IP = t->IP; a.s0 = t->b16_s0;
+  a.in_mu = m->has_in_scaler ? m->d_blob + m->off_in_mu : nullptr;
+  a.in_sig = m->has_in_scaler ? m->d_blob + m->off_in_var : nullptr;
+  a.w0 = base + t->b16_f_off[0]; a.w1 = base + t->b16_f_off[1]; a.w2 = base + t->b16_f_off[2];
+  a.w0_stride = (size_t)(H / 32) * t->b16_s0 * 2 * 64; a.w1_stride = (size_t)(H / 32) * (H / 16) * 2 * 64;
+  a.w2_stride = (size_t)2 * (H / 16) * 2 * 64;
+  a.b0 = m->d_blob + m->off_b0; a.b1 = m->d_blob + m->off_b1; a.b2 = m->d_blob + m->off_b2; a.b2_ld = m->o_tiles * 32;
+  a.stats = reinterpret_cast<const float *>(base + t->b16_stats_off);
+  a.O = t->O; a.D = t->D;
+  if (exports) { a.x = t->x; a.h1 = t->h1; a.g1 = t->g1; a.h2 = t->h2; a.g2 = t->g2; a.opmax = t->opmax; }
+  a.o = t->o;
+  if (d_targets) {
+    a.targets = d_targets; a.loss_part = t->loss_part;
+    a.out_mu = m->has_out_scaler ? m->d_blob + m->off_out_mu : nullptr;
+    a.out_sig = m->has_out_scaler ? m->d_blob + m->off_out_var : nullptr;
+  }
+  a.tiles32 = cmbpo_ceil_div(rows, 32);
+  static bool attr = false;
+  if (!attr) {
+    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_train_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)fh_lds_bytes()));
+    attr = true;
+  }
+  hipLaunchKernelGGL(fwd_train_h_kernel, dim3(cmbpo_ceil_div(rows, kBhRows), t->E), dim3(kBhThreads), fh_lds_bytes(), s, a);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }
@@ -1769,9 +2137,9 @@ int launch_update(cmbpo_trainer *t, int apply, float lr_t, hipStream_t s) {
     a.bwd = bwd[l]; a.b_kg = b_kg[l]; a.b_stride = b_stride[l];
     a.lr_t = lr_t; a.b1 = t->b1; a.b2 = t->b2; a.eps = t->eps; a.apply = apply;
     a.wmax_part = nullptr;
-    if (t->b16 && l >= 1) {
+    if (t->b16) {
       float *wm = reinterpret_cast<float *>(reinterpret_cast<f16x8 *>(t->b16) + t->b16_stats_off) + (size_t)E * NSTAT;
-      a.wmax_part = l == 1 ? wm : wm + (size_t)E * t->b16_blocks[0];
+      a.wmax_part = wm + (size_t)E * ((l >= 1 ? t->b16_blocks[0] : 0) + (l >= 2 ? t->b16_blocks[1] : 0));
     }
     all.first[l] = blocks;
     blocks += (unsigned)((t->wsize[l] + kThreads - 1) / kThreads);
@@ -1841,8 +2209,14 @@ int launch_fused(cmbpo_trainer *t, const float *d_inputs, const float *d_targets
   return CMBPO_OK;
 }
 
+bool fwd_f16() {
+  static const bool on = !(getenv("CMBPO_TRAIN_FWD_F16") && getenv("CMBPO_TRAIN_FWD_F16")[0] == '0');
+  return on && train_f16();
+}
+
 int run_forward(cmbpo_trainer *t, const float *d_inputs, const int32_t *d_idx, int idx_stride, int rows, bool exports,
                 hipStream_t s, const float *d_targets = nullptr) {
+  if (t->b16 && t->b16_fwd && fwd_f16()) return launch_fwd_h(t, d_inputs, d_idx, idx_stride, rows, exports, s, d_targets);
   MlpKernelArgs a{};
   a.obs = d_inputs; a.obs_dim = t->I; a.act = nullptr; a.act_dim = 0;
   a.row_idx = d_idx; a.row_idx_stride = idx_stride;
@@ -1954,19 +2328,24 @@ extern "C" int cmbpo_trainer_create(cmbpo_trainer_t **out, cmbpo_mlp_t *m, int m
   t->loss_part = reinterpret_cast<double *>(P + olp);
   t->opmax = P + oom;
   if (H == 512 && !t->fused && t->OPk <= 64) {
-    // images for the f16 backward chain (bwd_chain_h_kernel); without them the fp32 kernel runs
+    // images for the f16 training kernels (bwd_chain_h_kernel, fwd_train_h_kernel); without them the fp32 kernels run
     t->b16_s3 = cmbpo_ceil_div(t->OPk, 16);
+    t->b16_s0 = cmbpo_ceil_div(t->IP, 16);
+    t->b16_fwd = t->prob && t->IP <= 64 && t->O <= 64 && m->o_tiles <= 2;
     const size_t w1t = (size_t)E * (H / 32) * (H / 16) * 2 * 64, w2t = (size_t)E * (H / 32) * t->b16_s3 * 2 * 64;
+    const size_t f0 = (size_t)E * (H / 32) * t->b16_s0 * 2 * 64, f2 = (size_t)E * 2 * (H / 16) * 2 * 64;
     t->b16_w2t_off = w1t;
-    t->b16_stats_off = w1t + w2t;
-    t->b16_blocks[0] = (int)((size_t)H * H / kThreads);
-    t->b16_blocks[1] = (int)((size_t)H * t->O / kThreads);
-    const size_t tail_floats = (size_t)E * NSTAT + (size_t)E * (t->b16_blocks[0] + t->b16_blocks[1]);
-    if (hipMalloc(&t->b16, (w1t + w2t) * 16 + tail_floats * sizeof(float)) != hipSuccess) {
+    t->b16_f_off[0] = w1t + w2t; t->b16_f_off[1] = t->b16_f_off[0] + f0; t->b16_f_off[2] = t->b16_f_off[1] + w1t;
+    t->b16_stats_off = t->b16_f_off[2] + f2;
+    t->b16_blocks[0] = (int)((size_t)t->I * H / kThreads);
+    t->b16_blocks[1] = (int)((size_t)H * H / kThreads);
+    t->b16_blocks[2] = (int)((size_t)H * t->O / kThreads);
+    const size_t tail_floats = (size_t)E * NSTAT + (size_t)E * (t->b16_blocks[0] + t->b16_blocks[1] + t->b16_blocks[2]);
+    if (hipMalloc(&t->b16, t->b16_stats_off * 16 + tail_floats * sizeof(float)) != hipSuccess) {
       (void)hipGetLastError();
       t->b16 = nullptr;
     } else {
-      (void)hipMemset(reinterpret_cast<char *>(t->b16) + (w1t + w2t) * 16, 0, tail_floats * sizeof(float));
+      (void)hipMemset(reinterpret_cast<char *>(t->b16) + t->b16_stats_off * 16, 0, tail_floats * sizeof(float));
     }
   }
   *out = t;

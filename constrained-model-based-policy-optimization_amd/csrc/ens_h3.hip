@@ -827,14 +827,6 @@ void cmbpo_internal_f16_pack(const cmbpo_mlp *m, int layer, void *dst, size_t ds
                      perm);
 }
 
-// the same from any fp32 pack in the MFMA layout [n-tile][k-group][lane][4] (the trainer's transposed packs, ens_train.hip)
-void cmbpo_internal_f16_pack_from(const float *src, size_t src_stride, int kg, int src_tiles, void *dst, size_t dst_stride, int n_tiles,
-                                  int slabs, int members, const float *stats, int layer, hipStream_t s) {
-  const long total = (long)n_tiles * slabs * 64 * members;
-  hipLaunchKernelGGL(h3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, src_stride, kg, src_tiles,
-                     reinterpret_cast<f16x8 *>(dst), dst_stride, n_tiles, slabs, members, stats, layer, 0);
-}
-
 static int g_h3_rt = getenv("CMBPO_ENS_H3_RT") ? atoi(getenv("CMBPO_ENS_H3_RT")) : 0;   // 0: by row count; 1 / 2 / 4 forces it
 extern "C" int cmbpo_set_ens_f16_row_tiles(int rt) {
   CMBPO_REQUIRE(rt == 0 || rt == 1 || rt == 2 || rt == 4, "cmbpo_set_ens_f16_row_tiles: 0 (by row count), 1, 2 or 4");

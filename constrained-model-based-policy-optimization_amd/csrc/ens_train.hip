@@ -1800,25 +1800,65 @@ __device__ __forceinline__ void adam_w(const AdamWArgs &p, unsigned block) {
   }
 }
 
-// the members' lifts for the f16 backward chain from the blocks' maxima: stats[e][4 l] = 2^k with max |W_l| 2^k in [2^13, 2^14),
-// stats[e][4 l + 3] = max |W_l| (the slots h3_stats_kernel fills for the forward images); grid (E, 3)
-__global__ __launch_bounds__(kThreads) void wmax_fold_kernel(const float *part0, int blocks0, const float *part1, int blocks1,
-                                                             const float *part2, int blocks2, float *stats) {
-  const int e = blockIdx.x, l = blockIdx.y;
-  const float *part = l == 0 ? part0 + (size_t)e * blocks0 : (l == 1 ? part1 + (size_t)e * blocks1 : part2 + (size_t)e * blocks2);
-  const int nb = l == 0 ? blocks0 : (l == 1 ? blocks1 : blocks2);
-  float m = 0.0f;
-  for (int i = threadIdx.x; i < nb; i += kThreads) m = fmaxf(m, part[i]);
+// Every f16 image of a training step in ONE launch.  Image i (of n_img): fp32 pack [n-tile][k-group][lane][4] of layer
+// layer[i] -> two-piece image [n-tile][k-slab 16][piece 2][lane 64] of 8 halves (the layout of h3_pack_kernel, plain k order),
+// lifted by the member's power of two, which every workgroup takes itself from the block maxima Adam left for the layer (a
+// member's fragments of an image are a whole number of 256-thread workgroups); the first workgroup of a member in an image that
+// `writes_stats` also leaves {lift, max |W|} in stats[e][4 l], [4 l + 3] for the kernels that unscale the products.
+struct PackAllArgs {
+  const float *src[5]; size_t src_stride[5];     // fp32 packs, floats per member
+  f16x8 *dst[5]; size_t dst_stride[5];           // images, 16-byte units per member
+  int kg[5], src_tiles[5], n_tiles[5], slabs[5], layer[5], writes_stats[5];
+  unsigned first[6];                             // workgroups [first[i], first[i + 1]) belong to image i
+  const float *wmax[3]; int blocks[3];           // per layer: [E][blocks] block maxima
+  float *stats;
+  int n_img, E;
+};
+
+__global__ __launch_bounds__(kThreads) void train_pack_all_kernel(const PackAllArgs p) {
+  int img = 0;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  for (int i = 1; i < 5; ++i)
+    if (i < p.n_img && blockIdx.x >= p.first[i]) img = i;
+  const int tid = threadIdx.x;
+  const long per = (long)p.n_tiles[img] * p.slabs[img] * 64;       // lanes of one member's image
+  const long idx = (long)(blockIdx.x - p.first[img]) * kThreads + tid;
+  const int e = (int)(idx / per);
+  const int l = p.layer[img];
+  // the member's largest |W| of this layer
   __shared__ float s_m[kThreads / 64];
-  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
+  float m = 0.0f;
+  {
+    const float *part = p.wmax[l] + (size_t)e * p.blocks[l];
+    for (int i = tid; i < p.blocks[l]; i += kThreads) m = fmaxf(m, part[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((tid & 63) == 0) s_m[tid >> 6] = m;
+    __syncthreads();
     m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
-    stats[(size_t)e * NSTAT + 4 * l] = pow2_lift(m);
-    stats[(size_t)e * NSTAT + 4 * l + 3] = m;
   }
+  const float scale = pow2_lift(m);
+  const int rem = (int)(idx - (long)e * per);
+  if (p.writes_stats[img] && rem == 0) {
+    p.stats[(size_t)e * NSTAT + 4 * l] = scale;
+    p.stats[(size_t)e * NSTAT + 4 * l + 3] = m;
+  }
+  const int lane = rem & 63, sl = (rem >> 6) % p.slabs[img], tile = (rem >> 6) / p.slabs[img];
+  const int r = lane & 31, h = lane >> 5;
+  const float *sp = p.src[img] + (size_t)e * p.src_stride[img];
+  const int kg = p.kg[img];
+  f16x8 p1, p2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 16 * sl + 8 * h + j;
+    float v = 0.0f;
+    if (tile < p.src_tiles[img] && (k >> 3) < kg) v = sp[(((size_t)tile * kg + (k >> 3)) * 64 + ((k >> 2) & 1) * 32 + r) * 4 + (k & 3)];
+    _Float16 q1, q2;
+    split_h(v * scale, q1, q2);
+    p1[j] = q1; p2[j] = q2;
+  }
+  f16x8 *d = p.dst[img] + (size_t)e * p.dst_stride[img] + ((size_t)tile * p.slabs[img] + sl) * 2 * 64 + lane;
+  d[0] = p1; d[64] = p2;
 }
 
 struct AdamBArgs {
@@ -2020,9 +2060,8 @@ bool bwd_f16() {
   return on && train_f16();
 }
 
-// the images of the f16 training kernels from the current packs: the members' lifts from the block maxima the last Adam step
-// (or weight load) left -- one small launch instead of a pass over the packs (h3_stats_kernel: 24 us) -- then one pack launch
-// per image
+// the images of the f16 training kernels from the current packs, in one launch (train_pack_all_kernel): the members' lifts come
+// from the block maxima the last Adam step (or weight load) left, not from a pass over the packs (h3_stats_kernel: 24 us)
 int prepare_f16(cmbpo_trainer *t, hipStream_t s) {
   cmbpo_mlp *m = t->m;
   if (t->b16_version == m->pack_version) return CMBPO_OK;
@@ -2030,21 +2069,35 @@ int prepare_f16(cmbpo_trainer *t, hipStream_t s) {
   f16x8 *base = reinterpret_cast<f16x8 *>(t->b16);
   float *stats = reinterpret_cast<float *>(base + t->b16_stats_off);
   float *wm0 = stats + (size_t)E * NSTAT, *wm1 = wm0 + (size_t)E * t->b16_blocks[0], *wm2 = wm1 + (size_t)E * t->b16_blocks[1];
-  hipLaunchKernelGGL(wmax_fold_kernel, dim3(E, 3), dim3(kThreads), 0, s, wm0, t->b16_blocks[0], wm1, t->b16_blocks[1], wm2,
-                     t->b16_blocks[2], stats);
   const size_t w1t_stride = (size_t)(H / 32) * (H / 16) * 2 * 64, w2t_stride = (size_t)(H / 32) * t->b16_s3 * 2 * 64;
-  cmbpo_internal_f16_pack_from(t->wpb1, (size_t)(H / 32) * (H / 8) * 256, H / 8, H / 32, base, w1t_stride, H / 32, H / 16, E, stats, 1, s);
-  cmbpo_internal_f16_pack_from(t->wpb2, (size_t)(H / 32) * (t->OPk / 8) * 256, t->OPk / 8, H / 32, base + t->b16_w2t_off, w2t_stride,
-                               H / 32, t->b16_s3, E, stats, 2, s);
+  PackAllArgs pa{};
+  pa.wmax[0] = wm0; pa.wmax[1] = wm1; pa.wmax[2] = wm2;
+  for (int l = 0; l < 3; ++l) pa.blocks[l] = t->b16_blocks[l];
+  pa.stats = stats; pa.E = E;
+  int n = 0;
+  unsigned blocks = 0;
+  auto add = [&](const float *src, size_t src_stride, int kg, int src_tiles, f16x8 *dst, size_t dst_stride, int n_tiles, int slabs,
+                 int layer, int writes) {
+    pa.src[n] = src; pa.src_stride[n] = src_stride; pa.kg[n] = kg; pa.src_tiles[n] = src_tiles;
+    pa.dst[n] = dst; pa.dst_stride[n] = dst_stride; pa.n_tiles[n] = n_tiles; pa.slabs[n] = slabs; pa.layer[n] = layer;
+    pa.writes_stats[n] = writes;
+    pa.first[n] = blocks;
+    blocks += (unsigned)((size_t)n_tiles * slabs * 64 * E / kThreads);
+    ++n;
+  };
+  add(t->wpb1, (size_t)(H / 32) * (H / 8) * 256, H / 8, H / 32, base, w1t_stride, H / 32, H / 16, 1, 1);
+  add(t->wpb2, (size_t)(H / 32) * (t->OPk / 8) * 256, t->OPk / 8, H / 32, base + t->b16_w2t_off, w2t_stride, H / 32, t->b16_s3, 2, 1);
   if (t->b16_fwd) {
-    const float *blob = m->d_blob;
-    cmbpo_internal_f16_pack_from(blob + m->off_wp0, (size_t)(H / 32) * (t->IP / 8) * 256, t->IP / 8, H / 32, base + t->b16_f_off[0],
-                                 (size_t)(H / 32) * t->b16_s0 * 2 * 64, H / 32, t->b16_s0, E, stats, 0, s);
-    cmbpo_internal_f16_pack_from(blob + m->off_wp1, (size_t)(H / 32) * (H / 8) * 256, H / 8, H / 32, base + t->b16_f_off[1], w1t_stride,
-                                 H / 32, H / 16, E, stats, 1, s);
-    cmbpo_internal_f16_pack_from(blob + m->off_wp2, (size_t)m->o_tiles * (H / 8) * 256, H / 8, m->o_tiles, base + t->b16_f_off[2],
-                                 (size_t)2 * (H / 16) * 2 * 64, 2, H / 16, E, stats, 2, s);
+    float *blob = m->d_blob;
+    add(blob + m->off_wp0, (size_t)(H / 32) * (t->IP / 8) * 256, t->IP / 8, H / 32, base + t->b16_f_off[0],
+        (size_t)(H / 32) * t->b16_s0 * 2 * 64, H / 32, t->b16_s0, 0, 1);
+    add(blob + m->off_wp1, (size_t)(H / 32) * (H / 8) * 256, H / 8, H / 32, base + t->b16_f_off[1], w1t_stride, H / 32, H / 16, 1, 0);
+    add(blob + m->off_wp2, (size_t)m->o_tiles * (H / 8) * 256, H / 8, m->o_tiles, base + t->b16_f_off[2], (size_t)2 * (H / 16) * 2 * 64, 2,
+        H / 16, 2, 0);
   }
+  pa.first[n] = blocks;
+  pa.n_img = n;
+  hipLaunchKernelGGL(train_pack_all_kernel, dim3(blocks), dim3(kThreads), 0, s, pa);
   CMBPO_HIP_CHECK(hipGetLastError());
   t->b16_version = m->pack_version;
   return CMBPO_OK;

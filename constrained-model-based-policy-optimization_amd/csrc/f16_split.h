@@ -151,6 +151,3 @@ void cmbpo_internal_f16_stats(const cmbpo_mlp *m, float *stats, hipStream_t s);
 // member's power of two; perm: k order of an accumulator tile used as the B operand (see h3_pack_kernel)
 void cmbpo_internal_f16_pack(const cmbpo_mlp *m, int layer, void *dst, size_t dst_stride, int n_tiles, int slabs, int perm,
                              const float *stats, hipStream_t s);
-// ... and from any fp32 pack in the same layout (src_stride: floats per member; kg k-groups and src_tiles n-tiles in the pack)
-void cmbpo_internal_f16_pack_from(const float *src, size_t src_stride, int kg, int src_tiles, void *dst, size_t dst_stride, int n_tiles,
-                                  int slabs, int members, const float *stats, int layer, hipStream_t s);

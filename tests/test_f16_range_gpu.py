@@ -75,14 +75,18 @@ def path_errors(hip_lib, pe, x, ref_mean, ref_logvar):
 
 
 def assert_f16_within_twice_fp32(errs, what):
-    """Every (member, row): err_f16 <= 2 * max(that member's worst fp32-MFMA row, FLOOR) -- errors relative to the
+    """Every (member, row): err_f16 <= 2 * max(that member's worst fp32-MFMA row, the members' mean worst row, FLOOR) -- errors relative to the
     (member, row)'s own output scale, so a small row is not hidden behind a large one -- and the same over everything.
     (Row by row the two paths' errors are a few roundings in different orders: their ratio scatters by more than 2 both
     ways; tools/probe_f16_range.py prints the quantiles.)"""
     report = {k: (float(v[0].max()), float(v[1].max())) for k, v in errs.items()}
     for part, label in ((0, "mean"), (1, "logvar")):
         f16, f32 = errs["splitf16"][part], errs["fp32mfma"][part]
-        bound = 2.0 * np.maximum(f32.max(axis=1, keepdims=True), FLOOR)
+        # (a member's worst fp32 row is itself a maximum over a few thousand rounding patterns: it scatters by 2x from
+        # member to member of one ensemble -- 1.2e-6 .. 2.2e-6 on the trained AntSafe model -- so a member is not held
+        # below the ensemble's typical worst case)
+        worst = f32.max(axis=1, keepdims=True)
+        bound = 2.0 * np.maximum(np.maximum(worst, worst.mean()), FLOOR)
         assert (f16 <= bound).all(), \
             f"{what}/{label}: f16 path per member {f16.max(axis=1)} vs fp32-MFMA path {f32.max(axis=1)}; all: {report}"
         assert f16.max() <= 2.0 * max(f32.max(), FLOOR), f"{what}/{label}: {report}"

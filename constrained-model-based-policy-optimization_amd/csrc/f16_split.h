@@ -104,13 +104,13 @@ __device__ __forceinline__ void epi_stage(Epi4 &s, const f32x16 &d, int q, float
       if (PIN) asm volatile("" : "+v"(s.z[0]), "+v"(s.z[1]), "+v"(s.z[2]), "+v"(s.z[3]));
     }
   } else if constexpr (K == 8) {
-    s.q1[0] = s.q1[1] = 0u;
     // the second factor of the split's products: the lift, or sigma tn of the value itself
     const float m0 = FUSE ? s.e[0] : tn, m1 = FUSE ? s.e[1] : tn, m2 = FUSE ? s.e[2] : tn, m3 = FUSE ? s.e[3] : tn;
     // (hipcc pads no hazard behind an asm statement: where the pieces feed an MFMA straight from the registers -- the
     // tail, PIN == false -- the wait states between a VALU write and an MFMA's operand read stand inside the string)
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(s.q1[0]) : "v"(s.z[0]), "v"(m0));
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(s.q1[1]) : "v"(s.z[2]), "v"(m2));
+    // (the low halves are written first, "=&v": the registers need no initial value -- a v_mov each otherwise)
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(s.q1[0]) : "v"(s.z[0]), "v"(m0));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(s.q1[1]) : "v"(s.z[2]), "v"(m2));
     if constexpr (PIN) {
       asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(s.q1[0]) : "v"(s.z[1]), "v"(m1));
       asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(s.q1[1]) : "v"(s.z[3]), "v"(m3));
@@ -120,10 +120,9 @@ __device__ __forceinline__ void epi_stage(Epi4 &s, const f32x16 &d, int q, float
     }
     if (PIN) asm volatile("" : "+v"(s.q1[0]), "+v"(s.q1[1]));
   } else if constexpr (K == 9) {
-    s.q2[0] = s.q2[1] = 0u;
     const float m0 = FUSE ? s.e[0] : tn, m1 = FUSE ? s.e[1] : tn, m2 = FUSE ? s.e[2] : tn, m3 = FUSE ? s.e[3] : tn;
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(s.q2[0]) : "v"(s.z[0]), "v"(m0), "v"(s.q1[0]));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(s.q2[1]) : "v"(s.z[2]), "v"(m2), "v"(s.q1[1]));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(s.q2[0]) : "v"(s.z[0]), "v"(m0), "v"(s.q1[0]));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(s.q2[1]) : "v"(s.z[2]), "v"(m2), "v"(s.q1[1]));
     if constexpr (PIN) {
       asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(s.q2[0]) : "v"(s.z[1]), "v"(m1), "v"(s.q1[0]));
       asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(s.q2[1]) : "v"(s.z[3]), "v"(m3), "v"(s.q1[1]));

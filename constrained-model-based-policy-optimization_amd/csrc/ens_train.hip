@@ -2325,8 +2325,16 @@ extern "C" int cmbpo_trainer_create(cmbpo_trainer_t **out, cmbpo_mlp_t *m, int m
       continue;
     }
     int wgs = (H / 128) * n_tiles[l] * E;
-    if (H == 512) wgs = (l == 1) ? (H / 256) * (H / 128) * E : cmbpo_ceil_div(l == 0 ? t->IP : t->OPk, 64) * E;
-    int ks = (H == 512) ? 512 / wgs : cmbpo_ceil_div(512, wgs);   // 512-wide: one full round of 2 workgroups per CU
+    int ks = cmbpo_ceil_div(512, wgs);
+    if (H == 512) {
+      // 512-wide: the three GEMMs are ONE launch (wgrad_all_kernel) -- together they should fill one round of two
+      // workgroups per CU, not one round each.  Measured on the f16 kernels (tools/sweep_wgrad_ks.sh, E = 7: 6 for the
+      // square layer and 8 for the narrow ones against round 2's 9 / 16: 284 -> 243 us per step at batch 2048, 193 -> 180 at
+      // 512, 953 -> 919 at 8192): fewer, longer workgroups hide the operand loads better and leave Adam fewer partials.
+      const int narrow = (cmbpo_ceil_div(t->IP, 64) + cmbpo_ceil_div(t->OPk, 64)) * E * 8;
+      const int square = (H / 256) * (H / 128) * E;
+      ks = (l == 1) ? (int)(0.85f * (float)(512 - narrow) / (float)square) : 8;
+    }
     if (const char *env = getenv("CMBPO_WGRAD_KS")) {   // tuning aid: grid K split of the square layer
       if (l == 1 && atoi(env) > 0) ks = atoi(env);
     }

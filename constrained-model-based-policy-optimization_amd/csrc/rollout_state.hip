@@ -395,7 +395,15 @@ __global__ __launch_bounds__(256) void store_stats_kernel(const cmbpo_rollout_t 
 // launch boundary (decide 2 x 5, finish 5, store 9 + 6 us of a 140 us step at 1000 branches).  Up to kBookMax alive rows
 // one 1024-thread workgroup walks them in a fixed order: same decisions, same per-branch arithmetic, the step's sums added
 // in a fixed tree.  (Single-rank path: the cross-shard budget exchange keeps the separate kernels.)
-constexpr int kBookMax = 4096;
+// Round 3 (tools/sweep_book_max.sh): with the large-batch step's launches pipelined and its actor ahead of the host's wait, the
+// separate kernels win from ~1000 rows on (4 % at 1250 and 2500 rows, 8 % at 4000; the one-workgroup path wins by 5 - 10 % at
+// 400 - 700): the threshold came down from 4096.  (CMBPO_BOOK_MAX: 0 .. 65536; the kernels walk any count)
+constexpr int kBookMaxDefault = 1024;
+static const int kBookMax = [] {
+  const char *e = getenv("CMBPO_BOOK_MAX");
+  const int v = e ? atoi(e) : kBookMaxDefault;
+  return v < 0 ? 0 : (v > 65536 ? 65536 : v);
+}();
 
 // spec (cmbpo_rollout_run's look-ahead): the step was enqueued before the host saw the previous step's counters -- it is void
 // when that step raised the halt word (book_post_kernel)

@@ -56,8 +56,11 @@ __device__ __forceinline__ float clip_np(float x, float lo, float hi) { return x
 
 // EC: the ensemble size at compile time (0: read it at run time) -- with a run-time size the member loops are unrolled to
 // kEMax and masked: 56 pair terms computed and selected for the 42 that exist, a third more instructions
+#ifndef POST_WAVES
+#define POST_WAVES 5      // waves per SIMD the register allocation aims at (swept 4 / 5 / 6 / 8: 57.7 / 51.1 / 51.3 / 77.4 us at 100 k rows)
+#endif
 template <int EC>
-__global__ __launch_bounds__(kThreads) void fakeenv_post_kernel(const PostArgs p) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(POST_WAVES, POST_WAVES))) void fakeenv_post_kernel(const PostArgs p) {
   extern __shared__ float sm[];
   const int D = p.obs_dim;
   float *s_dkl = sm;                  // [kRows][D]

@@ -27,6 +27,8 @@ struct CfNet {
   const f16x8 *w0, *w1;          // images [member][n-tile][slab][piece][lane]
   size_t w0_stride, w1_stride;   // per member, 16-B units
   const float *b0, *b1, *w2, *b2;   // [E][128], [E][128], packed W2 ([E] x wp2_stride float4), [E][32]
+  const float *cst;                 // [E][3][128]: b0 log2(e) | b1 log2(e) | W2[:, 0] ln 2 (the epilogues work on z log2(e): one multiply
+                                    // less per activation, cf16_consts_kernel)
   size_t w2_stride;              // floats per member of the packed W2
   const float *stats;            // [E][NSTAT]
   const float *in_mu, *in_sig, *out_mu, *out_sig;   // or NULL
@@ -156,7 +158,8 @@ __global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
   // ---- h1 = swish(. + b0), lifted and split: accumulator registers 8 half .. + 7 of tile t are slab 2 t + half of layer 1
   f16x8 bf[S1][2];
   {
-    const float *b0 = N.b0 + (size_t)e * HC;
+    const float *b0 = N.cst + (size_t)e * 3 * HC;            // b0 log2(e)
+    const float inv0l = inv0 * kLog2e, it1 = 1.0f / (t1 * kLn2);
     u32x4 bu[S1][2];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
       for (int q = 0; q < 4; ++q) {
         const f32x4 bv = *reinterpret_cast<const f32x4 *>(b0 + 32 * t + 8 * q + 4 * hh);
         Epi4 es;
-        epi_all<false>(es, acc[t], q, inv0, bv, t1);
+        epi_all<false, true, true>(es, acc[t], q, inv0l, bv, it1);     // (pre-scaled operands, the lift in the reciprocal: f16_split.h)
         const int S = 2 * t + (q >> 1), o = 2 * (q & 1);
         bu[S][0][o] = es.q1[0]; bu[S][0][o + 1] = es.q1[1];
         bu[S][1][o] = es.q2[0]; bu[S][1][o + 1] = es.q2[1];
@@ -184,17 +187,22 @@ __global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
   // ---- h2 = swish(. + b1); output = h2 . W2[:, 0] + b2; output scaler ----------------------------------------------------
   float dot = 0.0f;
   {
-    const float *b1 = N.b1 + (size_t)e * HC;
-    const float *w2 = N.w2 + (size_t)e * N.w2_stride;     // packed [k-group][lane (n, h)][4]: (k, n = 0) at ((k >> 3) * 64 + ((k >> 2) & 1) * 32) * 4 + (k & 3)
+    const float *b1 = N.cst + (size_t)e * 3 * HC + HC, *w2 = b1 + HC;     // b1 log2(e), W2[:, 0] ln 2
+    const float inv1l = inv1 * kLog2e;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int k0 = 32 * t + 8 * q + 4 * hh;
         const f32x4 bv = *reinterpret_cast<const f32x4 *>(b1 + k0);
-        const f32x4 wv = *reinterpret_cast<const f32x4 *>(w2 + ((size_t)(k0 >> 3) * 64 + ((k0 >> 2) & 1) * 32) * 4);
+        const f32x4 wv = *reinterpret_cast<const f32x4 *>(w2 + k0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) dot = __builtin_fmaf(swishf(__builtin_fmaf(acc[t][4 * q + s], inv1, bv[s])), wv[s], dot);
+        for (int s = 0; s < 4; ++s) {
+          // y = z log2(e);  swish(z) w = y sigma(z) (w ln 2): six instructions per activation
+          const float y = __builtin_fmaf(acc[t][4 * q + s], inv1l, bv[s]);
+          const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-y));
+          dot = __builtin_fmaf(y * sg, wv[s], dot);
+        }
       }
   }
   dot += __shfl_xor(dot, 32, 64);
@@ -345,7 +353,8 @@ __global__ __launch_bounds__(512) void critic_big_kernel(const CfArgs a, int ch_
       // h1 = swish(. + b0), lifted and split: accumulator registers 8 half .. + 7 of tile tt are slab 2 tt + half of layer 1
       f16x8 bf[S1][2];
       {
-        const float *b0 = N.b0 + (size_t)e * HC;
+        const float *b0 = N.cst + (size_t)e * 3 * HC;            // b0 log2(e)
+        const float inv0l = inv0 * kLog2e, it1 = 1.0f / (t1 * kLn2);
         u32x4 bu[S1][2];
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt)
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(512) void critic_big_kernel(const CfArgs a, int ch_
           for (int q = 0; q < 4; ++q) {
             const f32x4 bv = *reinterpret_cast<const f32x4 *>(b0 + 32 * tt + 8 * q + 4 * hh);
             Epi4 es;
-            epi_all<false>(es, acc[tt], q, inv0, bv, t1);
+            epi_all<false, true, true>(es, acc[tt], q, inv0l, bv, it1);
             const int S = 2 * tt + (q >> 1), o = 2 * (q & 1);
             bu[S][0][o] = es.q1[0]; bu[S][0][o + 1] = es.q1[1];
             bu[S][1][o] = es.q2[0]; bu[S][1][o + 1] = es.q2[1];
@@ -377,17 +386,21 @@ __global__ __launch_bounds__(512) void critic_big_kernel(const CfArgs a, int ch_
       // h2 = swish(. + b1); output = h2 . W2[:, 0] + b2; output scaler
       float dot = 0.0f;
       {
-        const float *b1 = N.b1 + (size_t)e * HC;
-        const float *w2 = N.w2 + (size_t)e * N.w2_stride;
+        const float *b1 = N.cst + (size_t)e * 3 * HC + HC, *w2 = b1 + HC;
+        const float inv1l = inv1 * kLog2e;
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int k0 = 32 * tt + 8 * q + 4 * hh;
             const f32x4 bv = *reinterpret_cast<const f32x4 *>(b1 + k0);
-            const f32x4 wv = *reinterpret_cast<const f32x4 *>(w2 + ((size_t)(k0 >> 3) * 64 + ((k0 >> 2) & 1) * 32) * 4);
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(w2 + k0);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) dot = __builtin_fmaf(swishf(__builtin_fmaf(acc[tt][4 * q + s], inv1, bv[s])), wv[s], dot);
+            for (int s = 0; s < 4; ++s) {
+              const float y = __builtin_fmaf(acc[tt][4 * q + s], inv1l, bv[s]);
+              const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-y));
+              dot = __builtin_fmaf(y * sg, wv[s], dot);
+            }
           }
       }
       dot += __shfl_xor(dot, 32, 64);
@@ -404,6 +417,16 @@ __global__ __launch_bounds__(512) void critic_big_kernel(const CfArgs a, int ch_
   }
 }
 
+// the epilogues' constants, pre-scaled once per pack: [e][0] = b0 log2(e), [e][1] = b1 log2(e), [e][2] = W2[:, 0] ln 2 (compact)
+__global__ void cf16_consts_kernel(const float *b0, const float *b1, const float *w2, size_t w2_stride, float *cst) {
+  const int e = blockIdx.x, t = threadIdx.x, f = t / HC, k = t - f * HC;
+  float v;
+  if (f == 0) v = b0[(size_t)e * HC + k] * kLog2e;
+  else if (f == 1) v = b1[(size_t)e * HC + k] * kLog2e;
+  else v = w2[(size_t)e * w2_stride + ((size_t)(k >> 3) * 64 + ((k >> 2) & 1) * 32) * 4 + (k & 3)] * kLn2;     // packed (k, n = 0)
+  cst[(size_t)e * 3 * HC + t] = v;
+}
+
 // (re)builds the two f16 images and the statistics of a 128-wide single-output ensemble when its packs changed
 int ensure_cf16(cmbpo_mlp *m, hipStream_t s) {
   const int E = m->ensemble;
@@ -415,7 +438,7 @@ int ensure_cf16(cmbpo_mlp *m, hipStream_t s) {
     m->h3_off[0] = 0;
     m->h3_off[1] = m->h3_stride[0] * E;
     m->h3_stats_off = m->h3_off[1] + m->h3_stride[1] * E;
-    const size_t bytes = m->h3_stats_off * 16 + (size_t)E * NSTAT * sizeof(float);
+    const size_t bytes = m->h3_stats_off * 16 + (size_t)E * NSTAT * sizeof(float) + (size_t)E * 3 * HC * sizeof(float);   // ... | stats | constants
     if (hipMalloc(&m->d_h3, bytes) != hipSuccess) {
       (void)hipGetLastError();
       m->d_h3 = nullptr;
@@ -430,6 +453,8 @@ int ensure_cf16(cmbpo_mlp *m, hipStream_t s) {
   f16x8 *base = reinterpret_cast<f16x8 *>(m->d_h3);
   cmbpo_internal_f16_pack(m, 0, base + m->h3_off[0], m->h3_stride[0], NT, S0, 0, stats, s);
   cmbpo_internal_f16_pack(m, 1, base + m->h3_off[1], m->h3_stride[1], NT, S1, 1, stats, s);
+  hipLaunchKernelGGL(cf16_consts_kernel, dim3(E), dim3(3 * HC), 0, s, m->d_blob + m->off_b0, m->d_blob + m->off_b1, m->d_blob + m->off_wp2,
+                     (size_t)m->o_tiles * (HC / 8) * 256, stats + (size_t)E * NSTAT);
   CMBPO_HIP_CHECK(hipGetLastError());
   m->h3_version = m->pack_version;
   return CMBPO_OK;
@@ -491,6 +516,7 @@ int cmbpo_internal_critic_pair_ride(cmbpo_mlp *v, cmbpo_mlp *vc, const float *d_
     n.b0 = blob + m->off_b0; n.b1 = blob + m->off_b1; n.b2 = blob + m->off_b2;
     n.w2 = blob + m->off_wp2; n.w2_stride = (size_t)m->o_tiles * (HC / 8) * 256;
     n.stats = reinterpret_cast<const float *>(reinterpret_cast<const char *>(m->d_h3) + m->h3_stats_off * 16);
+    n.cst = n.stats + (size_t)m->ensemble * NSTAT;
     n.in_mu = m->has_in_scaler ? blob + m->off_in_mu : nullptr;
     n.in_sig = m->has_in_scaler ? blob + m->off_in_var : nullptr;
     n.out_mu = m->has_out_scaler ? blob + m->off_out_mu : nullptr;

@@ -95,8 +95,26 @@ __device__ __forceinline__ void epi_stage(Epi4 &s, const f32x16 &d, int q, float
     if (PIN) asm volatile("" : "+v"(s.e[0]), "+v"(s.e[1]), "+v"(s.e[2]), "+v"(s.e[3]));
   } else if constexpr (K == 5 || K == 6) {
     constexpr int o = 2 * (K - 5);
-    s.e[o] = __builtin_amdgcn_rcpf(s.e[o]); s.e[o + 1] = __builtin_amdgcn_rcpf(s.e[o + 1]);
-    if (PIN) asm volatile("" : "+v"(s.e[o]), "+v"(s.e[o + 1]));
+#ifdef EPI_NEWTON_RCP
+    if constexpr (PIN && FUSE) {
+      // diagnostic: the reciprocal on the plain vector pipe (integer seed + three Newton steps, error ~5e-8) -- does a
+      // transcendental instruction cost the partner wave's MFMAs more than seven plain ones?
+#pragma unroll
+      for (int i = o; i < o + 2; ++i) {
+        const float d = fminf(s.e[i], 1.2676506e30f);
+        float rr = __uint_as_float(0x7EF311C7u - __float_as_uint(d));
+        rr = rr * __builtin_fmaf(-d, rr, 2.0f);
+        rr = rr * __builtin_fmaf(-d, rr, 2.0f);
+        rr = rr * __builtin_fmaf(-d, rr, 2.0f);
+        s.e[i] = rr;
+      }
+      asm volatile("" : "+v"(s.e[o]), "+v"(s.e[o + 1]));
+    } else
+#endif
+    {
+      s.e[o] = __builtin_amdgcn_rcpf(s.e[o]); s.e[o + 1] = __builtin_amdgcn_rcpf(s.e[o + 1]);
+      if (PIN) asm volatile("" : "+v"(s.e[o]), "+v"(s.e[o + 1]));
+    }
   } else if constexpr (K == 7) {
     if constexpr (!FUSE) {
 #pragma unroll

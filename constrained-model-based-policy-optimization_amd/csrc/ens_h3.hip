@@ -182,6 +182,9 @@ __device__ __forceinline__ void static_for(F &&f) {
 #ifndef H3_EPI_FUSE
 #define H3_EPI_FUSE 1       // diagnostic: 0 = round 2's epilogue (separate product z sigma(z), the lift in the split's FMAs)
 #endif
+#ifndef H3_STORE8
+#define H3_STORE8 1         // diagnostic: 0 = the outputs as 4-byte lane stores (round 2)
+#endif
 #ifndef H3_TAIL_RING
 #define H3_TAIL_RING 0      // diagnostic: 1 = W2 fragments through the two-slab ring for every shape (round 2's tail)
 #endif
@@ -580,6 +583,24 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
     auto store_unit = [&](int u) {
       // a row's means / variances are contiguous runs of `out` floats; lane = column of the pair
       const int rt = u / NPASS, pass = u % NPASS;
+      if (H3_STORE8 && NPASS == 1 && (out & 1) == 0) {
+        // even widths (every shipped task): 8-byte stores, two rows per instruction -- lanes 0 .. out - 1 carry row A's
+        // (mean | var) as `out` float pairs, lanes out .. 2 out - 1 row B's (rows are 8-byte aligned: out 4 bytes a row)
+        const int half = lane >= out ? 1 : 0, c = 2 * (lane - half * out);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int rl = wave + kWavesH * (2 * j + half);
+          const int rr = rowidx[32 * rt + rl];
+          const float *sp = stg + (size_t)(u & 1) * 32 * SWS + rl * SWS + c;
+          const float2 y = make_float2(sp[0], sp[1]);
+          if (rr >= 0 && lane < 2 * out) {
+            const size_t obase = ((size_t)e * p.ld_rows + rr) * out;
+            float *dst = c < out ? p.out0 + obase + c : p.out1 + obase + (c - out);
+            *reinterpret_cast<float2 *>(dst) = y;
+          }
+        }
+        return;
+      }
       const int n = 64 * pass + lane;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

@@ -87,6 +87,31 @@ __device__ __forceinline__ double block_max(double v, double *sm) {
   return t;
 }
 
+// NS block sums followed by NM block maxima with the barriers of ONE reduction: per value exactly the operations of block_sum /
+// block_max above (same shuffle trees, same order: same bits), results valid in thread 0.  `sm` needs (NS + NM) * 16 doubles.
+template <int NS, int NM>
+__device__ __forceinline__ void block_reduce_many(double (&v)[NS + NM], double *sm) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int k = 0; k < NS + NM; ++k) v[k] = k < NS ? wave_sum(v[k]) : wave_max(v[k]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NS + NM; ++k) sm[k * 16 + w] = v[k];
+  }
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int k = 0; k < NS + NM; ++k) {
+      double t = (lane < nw) ? sm[k * 16 + lane] : (k < NS ? 0.0 : -1e300);
+      v[k] = k < NS ? wave_sum(t) : wave_max(t);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NS + NM; ++k) v[k] = 0.0;
+  }
+}
+
 // ---- reset -------------------------------------------------------------------------------------
 __global__ void reset_kernel(const cmbpo_rollout_t r) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -410,6 +435,7 @@ static const int kBookMax = [] {
 __global__ __launch_bounds__(kScanThreads) void book_pre_kernel(const cmbpo_rollout_t r, int spec) {
   __shared__ int sm_i[17];
   __shared__ double sm_d[16];
+  __shared__ double sm_m[8 * 16];
   __shared__ int s_unc;
   const int tid = threadIdx.x;
   if (spec && r.iscal[CMBPO_I_HALT]) return;
@@ -424,8 +450,9 @@ __global__ __launch_bounds__(kScanThreads) void book_pre_kernel(const cmbpo_roll
       c += u ? 1.0 : 0.0;
       d += (double)r.dkl_t[b];
     }
-    c = block_sum(c, sm_d);
-    d = block_sum(d, sm_d);
+    double cd[2] = {c, d};
+    block_reduce_many<2, 0>(cd, sm_m);     // (one pair of barriers for both sums)
+    c = cd[0]; d = cd[1];
     if (tid == 0) {
       s_unc = (int)c;
       r.iscal[CMBPO_I_N_UNC] = (int)c;
@@ -497,9 +524,10 @@ __global__ __launch_bounds__(kScanThreads) void book_pre_kernel(const cmbpo_roll
   // (the vector fields -- obs, act, mu, log_std: 53 floats per row at AntSafe shapes -- are copied by store_vec_kernel on
   // many CUs: one workgroup moving them took 25 of this kernel's 34 us at 1000 rows)
   // (5) the step's sums into the accumulators (store_stats_kernel)
-  const double s0 = block_sum(a_cnt, sm_d), s1 = block_sum(a_cost, sm_d), s2 = block_sum(a_rew, sm_d);
-  const double s3 = block_sum(a_v, sm_d), s4 = block_sum(a_vc, sm_d), s5 = block_sum(a_epv, sm_d);
-  const double s6 = block_max(a_maxdkl, sm_d), s7 = block_max(a_maxret, sm_d);
+  // (the eight reductions behind one pair of barriers: sixteen of them were a third of this kernel at 1000 rows)
+  double red[8] = {a_cnt, a_cost, a_rew, a_v, a_vc, a_epv, a_maxdkl, a_maxret};
+  block_reduce_many<6, 2>(red, sm_m);
+  const double s0 = red[0], s1 = red[1], s2 = red[2], s3 = red[3], s4 = red[4], s5 = red[5], s6 = red[6], s7 = red[7];
   if (tid == 0 && s0 > 0.0) {
     const double dkl_mean = r.dscal[CMBPO_D_DKL_SUM_T] / (double)n;  // np.mean over the rows stepped
     r.iscal[CMBPO_I_N_STORED] += (int)s0;

@@ -45,6 +45,8 @@ struct CfArgs {
   // the critics are evaluated at -- the step after this one then starts without a policy launch)
   int has_pol;
   PfArgs pol;
+  int has_store;       // the vector half of the step's store rides along (CmbpoStoreVec, ens_mlp_internal.h)
+  CmbpoStoreVec sv;
 };
 
 template <int S0>   // k-slabs of the input layer (obs_dim <= 16 S0)
@@ -95,6 +97,22 @@ __global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
       s_sig[n2][k] = (M.in_mu && k < a.obs_dim) ? M.in_sig[kc] : 1.0f;
     }
     __syncthreads();
+    if (a.has_store) {
+      // the tile's rows of the step's store: requested here, complete behind the next barrier -- long before the rider
+      // (this workgroup's own) writes the next step's actions over act / mu / log_std of these rows
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int dim = a.sv.dim[f];
+        const float inv = 1.0f / (float)dim;
+        for (int i = tid; i < 32 * dim; i += blockDim.x) {
+          const int b = (int)(((float)i + 0.5f) * inv);   // i / dim (exact: i < 2^16)
+          const int d = i - b * dim;
+          const int slot = rows[b];
+          if (slot >= 0 && !a.sv.fin_code[slot])
+            a.sv.dst[f][(a.sv.col_off + (size_t)slot) * dim + d] = a.sv.src[f][(size_t)slot * dim + d];
+        }
+      }
+    }
     for (int i = tid; i < 32 * KP; i += blockDim.x) {      // unconditional loads (clamped), the selection is on the values
       const int b = i / KP, k = i - b * KP;
       const int rr = rows[b];
@@ -492,7 +510,8 @@ bool cmbpo_internal_critic_pair_can_ride(const cmbpo_mlp *v, const cmbpo_mlp *vc
 // the critics at d_obs and -- if policy != NULL -- the actor at the same rows in the same launch (d_eps, outputs slot indexed)
 int cmbpo_internal_critic_pair_ride(cmbpo_mlp *v, cmbpo_mlp *vc, const float *d_obs, int obs_dim, const int32_t *d_row_idx,
                                     const int32_t *d_n_rows, int n_rows, float *d_v, float *d_vc, cmbpo_mlp *policy,
-                                    const float *d_eps, float *d_pi, float *d_logp, float *d_mu, float *d_ls, void *stream) {
+                                    const float *d_eps, float *d_pi, float *d_logp, float *d_mu, float *d_ls, void *stream,
+                                    const CmbpoStoreVec *store_vec) {
   CMBPO_REQUIRE(v && vc && d_obs && d_v && d_vc, "cmbpo_critic_pair_predict: NULL argument");
   CMBPO_REQUIRE(cmbpo_critic_pair_supported(v, vc), "cmbpo_critic_pair_predict: needs two loaded 128-wide swish ensembles of equal "
                                                     "size with one output (HEAD_DETMEAN)");
@@ -536,6 +555,13 @@ int cmbpo_internal_critic_pair_ride(cmbpo_mlp *v, cmbpo_mlp *vc, const float *d_
     a.pol.obs = d_obs; a.pol.eps = d_eps; a.pol.row_idx = d_row_idx; a.pol.n_rows_dev = d_n_rows; a.pol.n_rows = n_rows;
     a.pol.pi = d_pi; a.pol.logp = d_logp; a.pol.mu = d_mu; a.pol.ls = d_ls;
     a.has_pol = 1;
+  }
+  a.has_store = 0;
+  if (store_vec != nullptr) {
+    CMBPO_REQUIRE(d_row_idx != nullptr && n_rows < cmbpo_internal_critic_big_min() && store_vec->fin_code,
+                  "critic pair: the store rides with the one-wave-per-member kernel on a row list only");
+    a.sv = *store_vec;
+    a.has_store = 1;
   }
   // large batches without a rider: members one after the other with their weights in LDS (critic_big_kernel)
   if (!a.has_pol && n_rows >= cmbpo_internal_critic_big_min()) {

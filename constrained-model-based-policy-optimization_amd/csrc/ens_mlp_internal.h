@@ -85,8 +85,19 @@ int cmbpo_internal_policy_f16_args(cmbpo_mlp *m, void *pf_args, int *s0_out, hip
 // both critics and, riding along as one more wave per tile, the actor at the same rows (critic_f16.hip)
 int cmbpo_internal_critic_big_min();
 bool cmbpo_internal_critic_pair_can_ride(const cmbpo_mlp *v, const cmbpo_mlp *vc, const cmbpo_mlp *policy);
+// optional passenger of the critics' launch at small batches: the vector half of the rollout step's store (obs, act, mu, log_std
+// of every row that was not finished before the store -> column `col_off / B` of the buffers), copied by each tile's workgroup for
+// its own 32 rows before the rider may overwrite the per-step arrays (store_vec_kernel as a launch of its own otherwise)
+struct CmbpoStoreVec {
+  const float *src[4];
+  float *dst[4];
+  int dim[4];
+  const uint8_t *fin_code;
+  size_t col_off;        // ptr * B: first row of the column
+};
 int cmbpo_internal_critic_pair_ride(cmbpo_mlp *v, cmbpo_mlp *vc, const float *d_obs, int obs_dim, const int32_t *d_row_idx,
                                     const int32_t *d_n_rows, int n_rows, float *d_v, float *d_vc, cmbpo_mlp *policy,
-                                    const float *d_eps, float *d_pi, float *d_logp, float *d_mu, float *d_ls, void *stream);
+                                    const float *d_eps, float *d_pi, float *d_logp, float *d_mu, float *d_ls, void *stream,
+                                    const CmbpoStoreVec *store_vec = nullptr);
 // HEAD_DETMEAN, 128-wide, swish, one output (the critics) on the same matrix path
 int cmbpo_internal_launch_critic_split(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s);

@@ -1231,12 +1231,19 @@ extern "C" int cmbpo_rollout_book_pre(const cmbpo_rollout_t *r, int n_alive, voi
   return CMBPO_OK;
 }
 
-// the same for a step enqueued ahead of the previous step's counters (cmbpo_rollout_run): n_alive is an upper bound
-int cmbpo_internal_book_pre_spec(const cmbpo_rollout_t *r, int n_alive, void *stream) {
+// the same inside cmbpo_rollout_step / _run.  spec: the step was enqueued ahead of the previous step's counters (n_alive is an
+// upper bound then).  with_vec == 0: the vector half of the store rides in the critics' launch (CmbpoStoreVec) instead of
+// store_vec_kernel.
+int cmbpo_internal_book_pre(const cmbpo_rollout_t *r, int n_alive, int spec, int with_vec, void *stream) {
   if (int rc = check_rollout(r, "cmbpo_rollout_book_pre")) return rc;
-  CMBPO_REQUIRE(n_alive >= 1 && n_alive <= kBookMax && !r->use_host_budget && r->ptr < r->T, "book_pre (look-ahead): bad state");
-  hipLaunchKernelGGL(book_pre_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r, 1);
-  hipLaunchKernelGGL(store_vec_kernel, dim3(cmbpo_ceil_div(n_alive, kStoreRows)), dim3(256), 0, (hipStream_t)stream, *r, 1);
+  CMBPO_REQUIRE(n_alive >= 1 && n_alive <= kBookMax && !r->use_host_budget && r->ptr < r->T, "book_pre (step): bad state");
+  CMBPO_REQUIRE(r->dkl_t && r->dkl_acc && r->cur_obs && r->act_t && r->logp_t && r->mu_t && r->ls_t && r->v_t && r->vc_t && r->rew_t &&
+                    r->cost_t && r->epv_t && r->obs_buf && r->act_buf && r->mu_buf && r->ls_buf && r->rew_buf && r->val_buf &&
+                    r->cost_buf && r->cval_buf && r->logp_buf && r->adv_buf && r->ret_buf && r->cadv_buf && r->cret_buf,
+                "cmbpo_rollout_book_pre: NULL array");
+  hipLaunchKernelGGL(book_pre_kernel, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, *r, spec);
+  if (with_vec)
+    hipLaunchKernelGGL(store_vec_kernel, dim3(cmbpo_ceil_div(n_alive, kStoreRows)), dim3(256), 0, (hipStream_t)stream, *r, spec);
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }

@@ -16,7 +16,7 @@
 int cmbpo_internal_book_post_mirror(const cmbpo_rollout_t *r, int n_alive, uint32_t *d_host_out, uint32_t seq, int spec, int min_alive,
                                     double stop_total, void *stream);
 int cmbpo_internal_scalars_mirror(const cmbpo_rollout_t *r, uint32_t *d_host_out, uint32_t seq, void *stream);
-int cmbpo_internal_book_pre_spec(const cmbpo_rollout_t *r, int n_alive, void *stream);
+int cmbpo_internal_book_pre(const cmbpo_rollout_t *r, int n_alive, int spec, int with_vec, void *stream);
 int cmbpo_internal_store_nostats(const cmbpo_rollout_t *r, void *stream);
 int cmbpo_internal_finish_post_fold(const cmbpo_rollout_t *r, void *stream);
 int cmbpo_internal_spec_words(const cmbpo_rollout_t *r, int begin, void *stream);
@@ -58,10 +58,12 @@ static int step_impl(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy,
                                r->alive_idx, d_n, n_alive, w(r->next_obs), w(r->rew_t), const_cast<uint8_t *>(r->term_t), w(r->cost_t),
                                w(r->dkl_t), w(r->epv_t), nullptr, stream)))
     return rc;
-  if (ahead.on) {
-    if ((rc = cmbpo_internal_book_pre_spec(r, n_alive, stream))) return rc;
-  } else if (n_alive <= cmbpo_rollout_book_pre_max_rows() && !r->use_host_budget) {
-    if ((rc = cmbpo_rollout_book_pre(r, n_alive, stream))) return rc;     // decide + finish(PRE) + store in one launch
+  const bool small = ahead.on || (n_alive <= cmbpo_rollout_book_pre_max_rows() && !r->use_host_budget);
+  // small batches: decide + finish(PRE) + the store's scalar half in one launch; its vector half (obs, act, mu, log_std) rides
+  // in the critics' launch below where that is the one-wave-per-member kernel (8 us as a launch of its own at 1000 rows)
+  const bool vec_rides = small && cmbpo_critic_pair_supported(v, vc) && n_alive < cmbpo_internal_critic_big_min();
+  if (small) {
+    if ((rc = cmbpo_internal_book_pre(r, n_alive, ahead.on ? 1 : 0, vec_rides ? 0 : 1, stream))) return rc;
   } else {
     // large batches.  No branch can finish before the store unless the uncertainty test or a sample budget is on; the step's
     // sums are folded by the first workgroup of finish(POST) below instead of a launch of their own (nothing reads the
@@ -78,16 +80,25 @@ static int step_impl(const cmbpo_rollout_t *r, int n_alive, cmbpo_mlp_t *policy,
     static const int ride_max = getenv("CMBPO_RIDE_MAX_ROWS") ? atoi(getenv("CMBPO_RIDE_MAX_ROWS")) : (1 << 30);
     const bool ride = d_eps_next != nullptr && n_alive <= ride_max && n_alive < cmbpo_internal_critic_big_min() &&
                       cmbpo_internal_critic_pair_can_ride(v, vc, policy);     // (large batches: the member-after-member kernel)
+    CmbpoStoreVec sv{};
+    if (vec_rides) {
+      const float *src[4] = {r->cur_obs, r->act_t, r->mu_t, r->ls_t};
+      float *dst[4] = {r->obs_buf, r->act_buf, r->mu_buf, r->ls_buf};
+      const int dim[4] = {r->obs_dim, r->act_dim, r->act_dim, r->act_dim};
+      for (int f = 0; f < 4; ++f) { sv.src[f] = src[f]; sv.dst[f] = dst[f]; sv.dim[f] = dim[f]; }
+      sv.fin_code = r->fin_code;
+      sv.col_off = (size_t)r->ptr * (size_t)r->B;
+    }
     if ((rc = cmbpo_internal_critic_pair_ride(v, vc, r->next_obs, r->obs_dim, r->alive_idx, d_n, n_alive, w(r->v_n), w(r->vc_n),
                                               ride ? policy : nullptr, d_eps_next, w(r->act_t), w(r->logp_t), w(r->mu_t), w(r->ls_t),
-                                              stream)))
+                                              stream, vec_rides ? &sv : nullptr)))
       return rc;
     *next_ready = ride;
   } else {
     if ((rc = cmbpo_ens_predict_mean(v, r->next_obs, r->obs_dim, r->alive_idx, nullptr, n_alive, w(r->v_n), stream))) return rc;
     if ((rc = cmbpo_ens_predict_mean(vc, r->next_obs, r->obs_dim, r->alive_idx, nullptr, n_alive, w(r->vc_n), stream))) return rc;
   }
-  if (n_alive <= cmbpo_rollout_book_pre_max_rows() && !r->use_host_budget) {
+  if (small) {
     // finish(POST) + compaction in one launch (with the step's counters mirrored to the host, if asked)
     if ((rc = d_mirror ? cmbpo_internal_book_post_mirror(r, n_alive, d_mirror, seq, ahead.on ? 1 : 0, ahead.min_alive, ahead.stop_total,
                                                          stream)

@@ -167,7 +167,10 @@ class ModelSampler:
         self.n_budget_terminated = 0     # branches the `max_samples` rule ended early (model_sampler.py:282-287), this shard
         self._host = dict(total_samples=0.0, total_dkl=0.0)
         elites = np.asarray(self.env._model.elite_inds, dtype=np.int32)
-        self._elites = torch.as_tensor(elites, device=self.device)
+        if getattr(self, "_elites_host", None) is None or not np.array_equal(self._elites_host, elites):
+            # (uploaded again only when the elites changed: a host-to-device copy per reset otherwise)
+            self._elites_host = elites.copy()
+            self._elites = torch.as_tensor(elites, device=self.device)
         self._draws = None
         self._handles = None
 

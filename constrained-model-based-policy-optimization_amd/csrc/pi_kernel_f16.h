@@ -328,12 +328,10 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
   float *d1R = u1R;
   _Float16 *h1H = reinterpret_cast<_Float16 *>(h1R), *u1H = reinterpret_cast<_Float16 *>(u1R),
            *u2H = reinterpret_cast<_Float16 *>(u2R);
-  const f32x4 *h2R4 = reinterpret_cast<const f32x4 *>(h2R);
 
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);   // in an SGPR: every per-wave matrix pointer is scalar
   const int n_tiles = (p.n + BB - 1) / BB;
-  constexpr int IMG4 = BB * HID / 4;    // float4s of one dense [32][128] activation image
 
   // this wave's part of every matrix image
   const u32x4 *imgs[I_COUNT];

@@ -182,6 +182,10 @@ __device__ __forceinline__ void static_for(F &&f) {
 #ifndef H3_EPI_FUSE
 #define H3_EPI_FUSE 1       // diagnostic: 0 = round 2's epilogue (separate product z sigma(z), the lift in the split's FMAs)
 #endif
+#ifndef H3_PEEL_LAST
+#define H3_PEEL_LAST 1      // the fused loop's last step as an instance of its own, without the production of a chunk nobody reads
+                            // (0: round 2's branch-free loop; measured 1.212 / 1.215 -> 1.199 / 1.198 ms per 100 k-row forward)
+#endif
 #ifndef H3_STORE8
 #define H3_STORE8 1         // diagnostic: 0 = the outputs as 4-byte lane stores (round 2)
 #endif
@@ -448,9 +452,11 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
     // production of chunk c + 1 dealt out between them: a wave issues in order, so what stands between two MFMAs runs in the
     // shadow of the first.  Groups 0 .. S0-1 carry the layer-0 MFMAs of one input slab each (operands read one group
     // ahead), groups 4 .. 7 one quarter of the swish / lift / split epilogue each, one piece behind every MFMA.  The last
-    // step produces a chunk nobody reads (branch-free; its reads stay inside the workgroup's LDS / the member's weights).
-#pragma unroll 1
-    for (int c = 0; c < NCH; ++c) {
+    // step has no chunk to produce: it is an instance of its own (H3_PEEL_LAST).
+    // H3_PEEL_LAST: the last step as an instance of its own without the production of a chunk nobody reads (9 MFMAs, a
+    // quarter-chunk epilogue and its LDS stores per wave)
+    auto step = [&](auto LASTC, const int c) {
+      constexpr bool LAST = decltype(LASTC)::value;
       f16x8 wst;
       const bool stage_w0 = c + 2 < NCH;
       const int cw = stage_w0 ? c + 2 : NCH - 1;
@@ -463,11 +469,11 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
       f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
       read_bt(Bt[0], img, 0, 0);
       read_bt(Bt[1], img, 1 % RT, 1 / RT);
-      l0_read(l0, c + 1, 0);
+      if constexpr (!LAST) l0_read(l0, c + 1, 0);
 #pragma unroll
       for (int slot = 0; slot < 8; ++slot) {
-        if (slot >= 4) bv = l0_bias(c + 1, slot - 4);
-        if constexpr (G::W0_LDS) {
+        if (!LAST && slot >= 4) bv = l0_bias(c + 1, slot - 4);
+        if constexpr (G::W0_LDS && !LAST) {
           // W0 fragments of chunk c + 2 pass through four registers, one 1-KB piece at a time
           if (slot == 4) wst = w0e[((size_t)cw * W0P + wave) * 64 + lane];
           if (slot == 5 && W0P > kWavesH) {
@@ -499,7 +505,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
           else if (term == 1) ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[t][0], b2, ac, 0, 0, 0);
           else ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[t][0], b1, ac, 0, 0, 0);
 #ifndef H3_DIAG_NOL0
-          if (slot < S0 && i == 5) {          // layer-0 MFMAs of input slab `slot`, then the next slab's operands
+          if (!LAST && slot < S0 && i == 5) {          // layer-0 MFMAs of input slab `slot`, then the next slab's operands
             mm3(d, l0.a1, l0.a2, l0.b1, l0.b2);
             if (slot + 1 < S0) l0_read(l0, c + 1, slot + 1);
           }
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
 #ifdef H3_DIAG_NOEPI_LOOP
           if (false) {
 #else
-          if (slot >= 4) {
+          if (!LAST && slot >= 4) {
 #endif
             const int q = slot - 4;
             if (i == 0) epi_stage<0, true, true, H3_EPI_FUSE>(es, d, q, inv0_l, bv, t1_l);
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
         }
       }
       H3_STAMP(4);
-      if constexpr (G::W0_LDS) {
+      if constexpr (G::W0_LDS && !LAST) {
         if (stage_w0) {
           const int j = W0P > kWavesH ? wave + kWavesH : wave;
           if (j < W0P) w0buf[((size_t)(c & 1) * W0P + j) * 64 + lane] = wst;
@@ -534,7 +540,15 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
       }
       H3_BARRIER();
       H3_STAMP(5);
-    }
+    };
+#if H3_PEEL_LAST
+#pragma unroll 1
+    for (int c = 0; c < NCH - 1; ++c) step(std::false_type{}, c);
+    step(std::true_type{}, NCH - 1);
+#else
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) step(std::false_type{}, c);
+#endif
 
     // the next item's rows, biases and output bias: in flight behind the tail
     fetch_x(tid);

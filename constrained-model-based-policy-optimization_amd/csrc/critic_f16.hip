@@ -19,6 +19,9 @@
 
 namespace {
 
+#ifndef IN_SCALE_RCP
+#define IN_SCALE_RCP 1     // input scaler as (x - mu) (1 / sigma) (0: the IEEE division, diagnostic)
+#endif
 constexpr int HC = 128;          // hidden units
 constexpr int NT = HC / 32;      // n-tiles
 constexpr int S1 = HC / 16;      // k-slabs of layer 1
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
       const CfNet &M = a.net[n2];
       const int kc = k < a.obs_dim ? k : 0;
       s_mu[n2][k] = (M.in_mu && k < a.obs_dim) ? M.in_mu[kc] : 0.0f;
-      s_sig[n2][k] = (M.in_mu && k < a.obs_dim) ? M.in_sig[kc] : 1.0f;
+      s_sig[n2][k] = (M.in_mu && k < a.obs_dim) ? (IN_SCALE_RCP ? 1.0f / M.in_sig[kc] : M.in_sig[kc]) : 1.0f;      // 1 / sigma
     }
     __syncthreads();
     if (a.has_store) {
@@ -142,7 +145,9 @@ __global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = 16 * s + 8 * hh + j;
-      float x = (xraw[r * (KP + 1) + k] - s_mu[ni][k]) / s_sig[ni][k];   // TensorStandardScaler.transform, utils.py:156
+      // TensorStandardScaler.transform, utils.py:156, as (x - mu) (1 / sigma): within an ulp of the division (sixteen IEEE
+      // divisions per lane were a fifth of a (tile, member) unit's vector instructions)
+      float x = IN_SCALE_RCP ? (xraw[r * (KP + 1) + k] - s_mu[ni][k]) * s_sig[ni][k] : (xraw[r * (KP + 1) + k] - s_mu[ni][k]) / s_sig[ni][k];
       if (k >= a.obs_dim) x = 0.0f;
       xs[s][j] = x;
       m0 = fmaxf(m0, fabsf(x));
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(512) void critic_big_kernel(const CfArgs a, int ch_
     const CfNet &M = a.net[n2];
     const int kc = k < a.obs_dim ? k : 0;
     s_mu[n2 * KP + k] = (M.in_mu && k < a.obs_dim) ? M.in_mu[kc] : 0.0f;
-    s_sig[n2 * KP + k] = (M.in_mu && k < a.obs_dim) ? M.in_sig[kc] : 1.0f;
+    s_sig[n2 * KP + k] = (M.in_mu && k < a.obs_dim) ? (IN_SCALE_RCP ? 1.0f / M.in_sig[kc] : M.in_sig[kc]) : 1.0f;      // 1 / sigma
   }
   __syncthreads();
   for (int base = 0; base < tiles * 32 * KP; base += 512 * 4) {     // four requests in flight per thread
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(512) void critic_big_kernel(const CfArgs a, int ch_
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int k = 16 * s + 8 * hh + j;
-          float x = (xt[r * XS + k] - s_mu[ni * KP + k]) / s_sig[ni * KP + k];   // TensorStandardScaler.transform, utils.py:156
+          float x = IN_SCALE_RCP ? (xt[r * XS + k] - s_mu[ni * KP + k]) * s_sig[ni * KP + k] : (xt[r * XS + k] - s_mu[ni * KP + k]) / s_sig[ni * KP + k];   // TensorStandardScaler.transform, utils.py:156 (x 1 / sigma)
           if (k >= a.obs_dim) x = 0.0f;
           xs[s][j] = x;
           m0 = fmaxf(m0, fabsf(x));

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
   m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));
   const float t0 = pow2_lift(m0);
   const float bound1 = (st[1] * m0 + st[2]) * 1.001f, t1 = pow2_lift(bound1);
-  const float inv0 = 1.0f / (st[0] * t0), inv1 = 1.0f / (st[4] * t1);
+  const float inv0 = pow2_rcp(st[0] * t0), inv1 = pow2_rcp(st[4] * t1);     // (products of powers of two)
 
   f32x16 acc[NT];
   auto zero_acc = [&]() {
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512) void critic_pair_kernel(const CfArgs a) {
   f16x8 bf[S1][2];
   {
     const float *b0 = N.cst + (size_t)e * 3 * HC;            // b0 log2(e)
-    const float inv0l = inv0 * kLog2e, it1 = 1.0f / (t1 * kLn2);
+    const float inv0l = inv0 * kLog2e, it1 = pow2_rcp(t1) * kLog2e;
     u32x4 bu[S1][2];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(512) void critic_big_kernel(const CfArgs a, int ch_
       m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));
       const float t0 = pow2_lift(m0);
       const float bound1 = (st[1] * m0 + st[2]) * 1.001f, t1 = pow2_lift(bound1);
-      const float inv0 = 1.0f / (st[0] * t0), inv1 = 1.0f / (st[4] * t1);
+      const float inv0 = pow2_rcp(st[0] * t0), inv1 = pow2_rcp(st[4] * t1);     // (products of powers of two)
       f32x16 acc[NT];
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt)
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(512) void critic_big_kernel(const CfArgs a, int ch_
       f16x8 bf[S1][2];
       {
         const float *b0 = N.cst + (size_t)e * 3 * HC;            // b0 log2(e)
-        const float inv0l = inv0 * kLog2e, it1 = 1.0f / (t1 * kLn2);
+        const float inv0l = inv0 * kLog2e, it1 = pow2_rcp(t1) * kLog2e;
         u32x4 bu[S1][2];
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt)

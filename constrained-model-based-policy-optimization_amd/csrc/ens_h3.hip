@@ -386,7 +386,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
     // ---- layers 0 + 1, fused over the 8 chunks of h1 -------------------------------------------------------------------
     const int l0_tn = wave & (NTC - 1), l0_bt = wave / NTC;     // this wave's (n-tile, row-tile) pair of every chunk
     const float inv0_l = r_inv0[32 * l0_bt + r] * kLog2e;
-    const float t1_l = H3_EPI_FUSE ? 1.0f / (r_t1[32 * l0_bt + r] * kLn2) : r_t1[32 * l0_bt + r] * kLn2;     // (FUSE: the epilogue takes 1 / lift)
+    const float t1_l = H3_EPI_FUSE ? pow2_rcp(r_t1[32 * l0_bt + r]) * kLog2e : r_t1[32 * l0_bt + r] * kLn2;     // (FUSE: the epilogue takes 1 / lift)
     const _Float16 *xb0 = ximg + (size_t)(32 * l0_bt + r) * XSTR + 8 * hh;
     // layer-0 operands of one 16-deep slab: W0 fragments of the chunk (LDS copy) and this wave's rows of the x image
     struct L0Ops { f16x8 a1, a2, b1, b2; };
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
       auto stA = [&](auto RTI) {
         constexpr int rt = decltype(RTI)::value;
         const float inv1_l = r_inv1[32 * rt + r] * kLog2e;
-        const float t2_l = H3_EPI_FUSE ? 1.0f / (r_t2[32 * rt + r] * kLn2) : r_t2[32 * rt + r] * kLn2;
+        const float t2_l = H3_EPI_FUSE ? pow2_rcp(r_t2[32 * rt + r]) * kLog2e : r_t2[32 * rt + r] * kLn2;
         static_for<0, 8>([&](auto QD) {
           constexpr int quad = decltype(QD)::value, S = quad >> 1, jq = quad & 1, q = 2 * (S & 1) + jq;
           const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias1 + 64 * wave + 32 * (S >> 1) + 8 * q + 4 * hh);
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(kThreadsH, 2) void ens_h3_kernel(const H3Args a) {
       {
         u32x4 bfu[4][2];
         const float inv1_l = r_inv1[32 * rt + r] * kLog2e;
-        const float t2_l = H3_EPI_FUSE ? 1.0f / (r_t2[32 * rt + r] * kLn2) : r_t2[32 * rt + r] * kLn2;
+        const float t2_l = H3_EPI_FUSE ? pow2_rcp(r_t2[32 * rt + r]) * kLog2e : r_t2[32 * rt + r] * kLn2;
 #pragma unroll
         for (int S = 0; S < 4; ++S)
 #pragma unroll

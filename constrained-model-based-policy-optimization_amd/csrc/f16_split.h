@@ -23,6 +23,22 @@ __host__ __device__ __forceinline__ float pow2_lift(float v) {
   return c.f;
 }
 
+#ifndef POW2_RCP
+#define POW2_RCP 1     // 0: the IEEE division (diagnostic)
+#endif
+// 1 / x for x a power of two in the normal range (the lifts, the weights' scales and their products): the exponent negated, one
+// integer subtraction instead of the dozen instructions of an IEEE division
+__host__ __device__ __forceinline__ float pow2_rcp(float x) {
+#if POW2_RCP
+  union { float f; unsigned u; } c;
+  c.f = x;
+  c.u = 0x7F000000u - c.u;
+  return c.f;
+#else
+  return 1.0f / x;
+#endif
+}
+
 __device__ __forceinline__ void split_h(float a, _Float16 &p1, _Float16 &p2) {
   p1 = (_Float16)a;
   p2 = (_Float16)(a - (float)p1);   // exact difference

@@ -101,7 +101,7 @@ __device__ __forceinline__ void policy_tile(const PfArgs &a, int row0, int n_row
     }
   m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));
   const float t0 = pow2_lift(m0);
-  const float inv0 = 1.0f / (st[0] * t0), inv1 = 1.0f / (st[4] * T_H), inv2 = 1.0f / (st[8] * T_H);
+  const float inv0 = pow2_rcp(st[0] * t0), inv1 = pow2_rcp(st[4] * T_H), inv2 = pow2_rcp(st[8] * T_H);     // (powers of two)
 
   f32x16 acc[NTP];
   auto zero_acc = [&]() {

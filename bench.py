@@ -233,8 +233,9 @@ def ens_roofline(w, events):
         1: (PEAK_BF16_MFMA_TFLOPS / 6, "bf16 dense 2500 TFLOP/s / 6 MFMAs per f32 product",
             "ens_split_kernel (6 x v_mfma_f32_32x32x16_bf16 per f32 product)"),
         2: (PEAK_BF16_MFMA_TFLOPS / 3, "f16 dense 2500 TFLOP/s / 3 MFMAs per f32 product",
-            "ens_h3_kernel (3 x v_mfma_f32_32x32x16_f16 per f32 product; a forward is its full rounds of 128-row items <S0,OTP,4> "
-            "plus, when up to half a round is left over, that tail as 64-row items <S0,OTP,2>: avg_launch_ms covers both)"),
+            "ens_h3_kernel (3 x v_mfma_f32_32x32x16_f16 per f32 product; a forward is the full rounds of one item size -- 128 rows, "
+            "<S0,OTP,4>, at the headline shape -- plus, when the cost model prefers it, the leftovers as shorter items -- 64 rows, "
+            "<S0,OTP,2>, there -- in a launch of their own: avg_launch_ms covers both)"),
     }[path]
     return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "kernel": kernel, "avg_launch_ms": float(np.mean(k_ms)), "avg_rows_per_launch": float(np.mean(k_rows)),

@@ -899,18 +899,38 @@ int cmbpo_internal_launch_h3(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
   }
-  // rows per item: 128 when that still gives every CU an item, else 64, else 32 (an item's latency is the step's when the
-  // launch is a single round of items)
+  // rows per item: the fewest rounds of items x an item's time (measured alone on a CU, AntSafe shapes: 21 / 30 / 51 us at
+  // 32 / 64 / 128 rows -- an item's latency is the step's when the launch is a single round of items).  The full rounds of one
+  // item size may be followed by the leftovers at a SMALLER size in a launch of their own: a last round that would leave
+  // most CUs idle becomes one or two rounds of short items on all of them (100 000 rows x 7 members = 5474 items of 128 rows
+  // on 256 CUs: 21 full rounds + 98 items -> 196 items of 64 rows; 10 000 rows: 2 rounds of 128-row items + 41 items -> 164
+  // of 32 rows, 127 us by this model against 150 for five rounds of 64-row items).  An item is (member, row tile) in
+  // member-major order in every list, so a suffix of one list is a suffix of the others; a row's arithmetic does not depend
+  // on the item it travels in (tests: bitwise against the forced sizes).
   const int E = m->ensemble;
-  int RT = g_h3_rt;
+  static const int split_tail = getenv("CMBPO_ENS_H3_SPLIT_TAIL") ? atoi(getenv("CMBPO_ENS_H3_SPLIT_TAIL")) : 1;
+  static const int split_gap_us = getenv("CMBPO_ENS_H3_SPLIT_GAP") ? atoi(getenv("CMBPO_ENS_H3_SPLIT_GAP")) : 4;   // launch boundary
+  int RT = g_h3_rt, RT_tail = 0, full = 0, tail_start = 0;
   if (RT == 0) {
-    // fewest rounds of items x an item's time (measured alone on a CU, AntSafe shapes: 21 / 30 / 51 us at 32 / 64 / 128 rows)
     const int t_us[3] = {21, 30, 51}, rts[3] = {1, 2, 4};
     long best = -1;
     for (int i = 0; i < 3; ++i) {
       const long cost = (long)cmbpo_ceil_div(cmbpo_ceil_div(a.n_rows, 32 * rts[i]) * E, n_cu) * t_us[i];
       if (best < 0 || cost <= best) { best = cost; RT = rts[i]; }
     }
+    if (split_tail)
+      for (int i = 1; i < 3; ++i) {
+        const int tiles_m = cmbpo_ceil_div(a.n_rows, 32 * rts[i]), n_m = tiles_m * E;
+        const int fl = n_m / n_cu * n_cu, left = n_m - fl;
+        if (fl == 0 || left == 0) continue;
+        const int e0 = fl / tiles_m, t0 = fl - e0 * tiles_m;
+        for (int j = 0; j < i; ++j) {
+          const int tiles_t = cmbpo_ceil_div(a.n_rows, 32 * rts[j]);
+          const int start = e0 * tiles_t + (rts[i] / rts[j]) * t0, n_tail = tiles_t * E - start;
+          const long cost = (long)(fl / n_cu) * t_us[i] + (long)cmbpo_ceil_div(n_tail, n_cu) * t_us[j] + split_gap_us;
+          if (cost < best) { best = cost; RT = rts[i]; RT_tail = rts[j]; full = fl; tail_start = start; }
+        }
+      }
   }
   const int S0 = m->h3_s0, OTP = m->h3_otp;
   static bool attr_done[5][5][5] = {};
@@ -942,18 +962,9 @@ int cmbpo_internal_launch_h3(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
     CMBPO_HIP_CHECK(hipGetLastError());
     return CMBPO_OK;
   };
-  // The last round of 128-row items leaves most CUs idle when few items remain (100 000 rows x 7 members = 5474 items on 256
-  // CUs: 21 full rounds + 98 items).  Up to half a round of leftovers goes as 64-row items in a launch of its own: twice the
-  // items, all in one round, each ~0.6 of a 128-row item's time.  An item is (member, row tile) in member-major order in both
-  // lists, so a suffix of one list is a suffix of the other.
-  static const int split_tail = getenv("CMBPO_ENS_H3_SPLIT_TAIL") ? atoi(getenv("CMBPO_ENS_H3_SPLIT_TAIL")) : 1;
-  const int tiles4 = cmbpo_ceil_div(a.n_rows, 128), n4 = tiles4 * E, left = n4 % n_cu;
-  if (RT == 4 && split_tail && g_h3_rt == 0 && n4 >= 2 * n_cu && left > 0 && left <= n_cu / 2) {
-    const int full = n4 - left;
-    const int e0 = full / tiles4, t0 = full - e0 * tiles4;
-    const int tiles2 = cmbpo_ceil_div(a.n_rows, 64);
-    if (int rc = launch(4, 0, full)) return rc;
-    return launch(2, e0 * tiles2 + 2 * t0, -1);
+  if (RT_tail) {
+    if (int rc = launch(RT, 0, full)) return rc;
+    return launch(RT_tail, tail_start, -1);
   }
   return launch(RT, 0, -1);
 }

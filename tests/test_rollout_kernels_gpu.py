@@ -77,20 +77,22 @@ def test_ens_forward_f16_item_shapes(hip_lib, rt, task, n):
     assert hip_lib.cmbpo_set_ens_f16_row_tiles(3) < 0
 
 
-def test_ens_forward_tail_round_as_half_items(hip_lib):
-    """35 000 rows x 7 members = 1918 items of 128 rows on 256 CUs: 7 full rounds + 126 left over, which go as 64-row items
-    in a launch of their own (ens_h3.hip).  Every row against the oracle, and bitwise against the same forward with the
-    item size forced (no split)."""
+@pytest.mark.parametrize("task,n,forced", [("AntSafe-v2", 35000, 4), ("AntSafe-v2", 10000, 4), ("HalfCheetahSafe-v2", 10000, 2),
+                                           ("AntSafe-v2", 5000, 1), ("AntSafe-v2", 5761, 2), ("HumanoidSafe-v2", 20000, 4)])
+def test_ens_forward_tail_round_as_shorter_items(hip_lib, task, n, forced):
+    """The full rounds of one item size followed by the leftovers at a smaller one, in a launch of their own (ens_h3.hip; on
+    256 CUs with 7 members: 35 000 and 20 000 rows = 128-row items + a round of 64-row items, 10 000 and 5 000 rows = 128-row
+    items + 32-row items, 5 761 rows = 64-row items + 32-row items).  Every row against the oracle, and bitwise against the
+    same forward with one item size forced (a single launch, no split)."""
     _cuda()
-    rng = np.random.default_rng(4242)
-    m, ws, bs, sc_in, sc_out, obs_dim, act_dim = _dyn_model(rng, "AntSafe-v2")
-    n = 35000
+    rng = np.random.default_rng(4242 + n)
+    m, ws, bs, sc_in, sc_out, obs_dim, act_dim = _dyn_model(rng, task)
     x = rng.standard_normal((n, obs_dim + act_dim)).astype(np.float32)
     mean, var = m.predict_ensemble(x)
     rmean, rvar = refcpu.ens_forward(x, ws, bs, sc_in, sc_out)
     np.testing.assert_allclose(mean, rmean, rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(var, rvar, rtol=2e-3, atol=1e-6)
-    assert hip_lib.cmbpo_set_ens_f16_row_tiles(4) == 0       # forced 128-row items: one launch, no split
+    assert hip_lib.cmbpo_set_ens_f16_row_tiles(forced) == 0
     try:
         mean4, var4 = m.predict_ensemble(x)
     finally:

@@ -21,13 +21,13 @@ m = PE(obs_dim + act_dim, obs_dim + 1, hidden_dims=(512, 512), num_networks=E, n
 m.set_weights(ws, bs, synthetic.scaler(rng, obs_dim + act_dim), synthetic.scaler(rng, obs_dim + 1))
 lib = _lib.lib()
 lib.cmbpo_set_ens_f16_min_rows(0)
-for B in (128, 256, 512, 1000, 2000, 3000, 4000, 6000, 8000, 10000, 16000, 25000, 50000):
+for B in (128, 256, 512, 1000, 2000, 3000, 4000, 5000, 6000, 8000, 10000, 13000, 16000, 20000, 25000, 35000, 50000):
     obs = torch.randn(B, obs_dim, device="cuda") * 0.5
     act = torch.rand(B, act_dim, device="cuda") * 2 - 1
     mean = torch.empty(E, B, obs_dim + 1, device="cuda")
     var = torch.empty_like(mean)
     out = []
-    for path, rt in ((1, 0), (2, 4), (2, 2), (2, 1)):
+    for path, rt in ((1, 0), (2, 4), (2, 2), (2, 1), (2, 0)):
         lib.cmbpo_set_ens_matrix_path(path)
         lib.cmbpo_set_ens_f16_row_tiles(rt)
         for _ in range(5):
@@ -41,4 +41,5 @@ for B in (128, 256, 512, 1000, 2000, 3000, 4000, 6000, 8000, 10000, 16000, 25000
         e.record()
         torch.cuda.synchronize()
         out.append(s.elapsed_time(e) / iters * 1e3)
-    print(f"B={B:6d}  bf16x6 {out[0]:8.1f} us   f16x3 128-row {out[1]:8.1f}  64-row {out[2]:8.1f}  32-row {out[3]:8.1f} us", flush=True)
+    print(f"B={B:6d}  bf16x6 {out[0]:8.1f} us   f16x3 128-row {out[1]:8.1f}  64-row {out[2]:8.1f}  32-row {out[3]:8.1f}  cost model {out[4]:8.1f} us", flush=True)
+lib.cmbpo_set_ens_f16_row_tiles(0)

@@ -16,6 +16,9 @@
 #pragma once
 #include <utility>
 
+#ifndef PI_DEFER_DMA
+#define PI_DEFER_DMA 1      // 0: round 3's first form (the barrier that ends a tile waits for the next tile's saved activations)
+#endif
 constexpr float T_TANH = 16384.0f;      // |tanh| <= 1
 constexpr float T_TANH_INV = 1.0f / 16384.0f;
 constexpr int RSH = 2 * RS;             // row stride of a two-piece image, in halves
@@ -412,12 +415,24 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
   if constexpr (ACT_DMA) {
     if ((int)blockIdx.x < n_tiles) fetch_act(blockIdx.x, tid0 & 63);
   }
+  // with the saved activations the only batch column a product reads is log_std_old: fetched one tile ahead like x, so that
+  // the barrier that waits for the activations (vmcnt(0)) finds no younger load of this tile in front of it
+  constexpr bool LSO_PRE = ACT_DMA && PI_DEFER_DMA;
+  float lso_pre = 0.0f;
+  auto fetch_lso = [&](int t, int tid) {
+    const int er0 = t * BB + (tid & 31), a0 = tid >> 5;
+    lso_pre = (er0 < p.n && a0 < d.A) ? p.ls_old[(size_t)er0 * d.A + a0] : 0.0f;
+  };
+  if constexpr (LSO_PRE) {
+    if ((int)blockIdx.x < n_tiles) fetch_lso(blockIdx.x, tid0);
+  }
 #ifdef CMBPO_STAMPS
   unsigned long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = __builtin_amdgcn_s_memtime();
   const unsigned long long t_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
   int parity = 0;
+  float warm = 0.0f;       // (the warm-up touch of the next tile's saved activations: consumed where vmcnt is drained anyway)
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, parity ^= 1) {
     const int row0 = tile * BB;
     // the thread index is opaque per tile, or every per-lane address of the loop (matrix slabs, bias / batch pointers, ...)
@@ -462,7 +477,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
           e_cadv = p.cadv[er0];
         }
         if (a0 < d.A) {
-          if constexpr (MODE != MODE_GRAD) lso0 = p.ls_old[(size_t)er0 * d.A + a0];
+          if constexpr (MODE != MODE_GRAD && !LSO_PRE) lso0 = p.ls_old[(size_t)er0 * d.A + a0];
           if constexpr (MODE != MODE_FVP) e_act0 = p.act[(size_t)er0 * d.A + a0];
           if constexpr (MODE == MODE_EVAL) e_mu0 = p.mu_old[(size_t)er0 * d.A + a0];
         }
@@ -474,7 +489,16 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
       // ---- h1, h2 as cmbpo_pi_loss_grad left them (same parameters, same batch): the LDS block itself, so the products
       // see identical bits; it was requested behind the previous tile's dW2 (before the loop for the first tile) and the
       // barrier that ended that tile waited for it
-      lds_barrier();
+      if constexpr (PI_DEFER_DMA) {
+        // ... and THIS barrier publishes the block: its LDS-DMA (counted in vmcnt) was requested behind the previous tile's
+        // dW2 and has had the rest of that tile and this tile's staging to arrive (it used to be waited for by the barrier
+        // that ends a tile, a few hundred cycles after the request: ~14 % of a tile at that barrier)
+        lso0 = lso_pre;
+        __syncthreads();
+        asm volatile("" ::"v"(warm));   // the previous tile's warm-up load must be issued, its value is not used
+      } else {
+        lds_barrier();
+      }
       t_x = pow2_lift(__uint_as_float(mx[0]));
       it_x = pow2_inv(t_x);
     } else {
@@ -705,8 +729,10 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
     }
     PI_STAMP(10);
     // ---- weight gradients: K = the tile's samples ---------------------------------------------------
-    float warm = 0.0f;
     if (tile + (int)gridDim.x < n_tiles) fetch_x(tile + gridDim.x, tid);
+    if constexpr (LSO_PRE) {
+      if (tile + (int)gridDim.x < n_tiles) fetch_lso(tile + gridDim.x, tid);
+    }
     if constexpr (MODE == MODE_FVP && CACHED) {
       // touch one dword of each 128-B line of the NEXT tile's saved activations: they travel HBM -> L2 behind the
       // MFMAs below, and the loads at the top of the next iteration hit L2
@@ -732,9 +758,10 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel_h(const PiArgs p) {
       wgrad_s<true>(gW0[0], xR, XS, 0, t_x, d1R, RS, wave * 32, t_d1, it_x * it_d1, it_d1, gbias0, lane);
       if constexpr (N_IT == 2) wgrad_s<false>(gW0[N_IT - 1], xR, XS, 32, t_x, d1R, RS, wave * 32, t_d1, it_x * it_d1, 0.0f, unused, lane);
     }
-    asm volatile("" ::"v"(warm));   // the warm-up load must be issued, its value is not used
+    if constexpr (!(ACT_DMA && PI_DEFER_DMA)) asm volatile("" ::"v"(warm));   // the warm-up load must be issued, its value is not used
     ring_fill<ST>(R, imgs, lane);   // the next tile's first slabs: they land behind its staging
-    __syncthreads();                // (waits for the LDS-DMA of the next tile's saved activations as well)
+    if constexpr (ACT_DMA && PI_DEFER_DMA) lds_barrier();   // x / delta1 have no reader left; the activations are waited for later
+    else __syncthreads();           // (waits for the LDS-DMA of the next tile's saved activations as well)
     PI_STAMP(13);
   }
 #ifdef CMBPO_STAMPS

@@ -9,6 +9,7 @@
 // buffers make both the per-step store and the per-branch backward GAE recurrence coalesced
 // (adjacent lanes = adjacent branches).
 #include "common.h"
+#include <type_traits>
 
 #include <math.h>
 #include <stdlib.h>
@@ -1025,21 +1026,28 @@ __device__ __forceinline__ void flatten_vec_body(const cmbpo_rollout_t &r, const
       if (t < lens[bl]) smap[loffs[bl] - o0 + t] = (unsigned short)e;
     }
   }
-  constexpr int NU = 9;                       // 4 waves x 9 steps: T <= 36 in one pass
-  // obs (output 0)
-  flat_vec_in<NU>(tile, r.obs_buf + (size_t)b0 * D, D, nb, T, lmax, B, lane, wave, tid);
-  __syncthreads();
-  flat_vec_out(tile, fa.out[0] + (size_t)o0 * D, D, nb, T, cnt, o0, smap, tid);
-  __syncthreads();
-  // act (1), log_std (10), mu (11): three tiles side by side
-  const size_t ts = (size_t)vt * T * A;
-  flat_vec_in<NU>(tile, r.act_buf + (size_t)b0 * A, A, nb, T, lmax, B, lane, wave, tid);
-  flat_vec_in<NU>(tile + ts, r.ls_buf + (size_t)b0 * A, A, nb, T, lmax, B, lane, wave, tid);
-  flat_vec_in<NU>(tile + 2 * ts, r.mu_buf + (size_t)b0 * A, A, nb, T, lmax, B, lane, wave, tid);
-  __syncthreads();
-  flat_vec_out(tile, fa.out[1] + (size_t)o0 * A, A, nb, T, cnt, o0, smap, tid);
-  flat_vec_out(tile + ts, fa.out[10] + (size_t)o0 * A, A, nb, T, cnt, o0, smap, tid);
-  flat_vec_out(tile + 2 * ts, fa.out[11] + (size_t)o0 * A, A, nb, T, cnt, o0, smap, tid);
+  // 4 waves x NU steps per pass, every load of a pass in flight before the first LDS write: 9 covers T <= 36 in one pass; a
+  // rollout that ended after a few steps ('uncertainty' mode) takes the 2-step form -- steps past the last are clamped
+  // copies of it, and seven of nine were
+  auto body = [&](auto NUC) {
+    constexpr int NU = decltype(NUC)::value;
+    // obs (output 0)
+    flat_vec_in<NU>(tile, r.obs_buf + (size_t)b0 * D, D, nb, T, lmax, B, lane, wave, tid);
+    __syncthreads();
+    flat_vec_out(tile, fa.out[0] + (size_t)o0 * D, D, nb, T, cnt, o0, smap, tid);
+    __syncthreads();
+    // act (1), log_std (10), mu (11): three tiles side by side
+    const size_t ts = (size_t)vt * T * A;
+    flat_vec_in<NU>(tile, r.act_buf + (size_t)b0 * A, A, nb, T, lmax, B, lane, wave, tid);
+    flat_vec_in<NU>(tile + ts, r.ls_buf + (size_t)b0 * A, A, nb, T, lmax, B, lane, wave, tid);
+    flat_vec_in<NU>(tile + 2 * ts, r.mu_buf + (size_t)b0 * A, A, nb, T, lmax, B, lane, wave, tid);
+    __syncthreads();
+    flat_vec_out(tile, fa.out[1] + (size_t)o0 * A, A, nb, T, cnt, o0, smap, tid);
+    flat_vec_out(tile + ts, fa.out[10] + (size_t)o0 * A, A, nb, T, cnt, o0, smap, tid);
+    flat_vec_out(tile + 2 * ts, fa.out[11] + (size_t)o0 * A, A, nb, T, cnt, o0, smap, tid);
+  };
+  if (T <= 8) body(std::integral_constant<int, 2>{});
+  else body(std::integral_constant<int, 9>{});
 }
 
 // ROWS branches per workgroup: 64 (16 lanes x 16 bytes cover a step's row of the tile), or 16 for buffers too small to give
@@ -1072,27 +1080,33 @@ __device__ __forceinline__ void flatten_scalar_body(const cmbpo_rollout_t &r, co
   if (nb == ROWS && (B & 3) == 0) {
     // LPS lanes x 16 bytes = the tile's branches of one step; steps ts, ts + G, ...; every load of a pass is requested
     // before the first LDS write
-    constexpr int LPS = ROWS / 4, G = 256 / LPS, NUS = ROWS == 64 ? 3 : 1;
+    constexpr int LPS = ROWS / 4, G = 256 / LPS;
     const int l16 = tid % LPS, ts = tid / LPS;
-    for (int tb = ts; tb < lmax; tb += G * NUS) {
-      f32x4 v[8][NUS];
+    auto pass = [&](auto NUC) {
+      constexpr int NUS = decltype(NUC)::value;
+      for (int tb = ts; tb < lmax; tb += G * NUS) {
+        f32x4 v[8][NUS];
 #pragma unroll
-      for (int g = 0; g < 8; ++g)
+        for (int g = 0; g < 8; ++g)
 #pragma unroll
-        for (int u = 0; u < NUS; ++u) {
-          const int t = min(tb + G * u, T - 1);
-          v[g][u] = *reinterpret_cast<const f32x4 *>(ssrc[g] + (size_t)t * B + b0 + 4 * l16);
-        }
-#pragma unroll
-      for (int g = 0; g < 8; ++g)
-#pragma unroll
-        for (int u = 0; u < NUS; ++u)
-          if (tb + G * u < lmax) {
-            float *tl = tile + g * fs + (4 * l16) * TS + tb + G * u;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) tl[i * TS] = v[g][u][i];
+          for (int u = 0; u < NUS; ++u) {
+            const int t = min(tb + G * u, T - 1);
+            v[g][u] = *reinterpret_cast<const f32x4 *>(ssrc[g] + (size_t)t * B + b0 + 4 * l16);
           }
-    }
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+          for (int u = 0; u < NUS; ++u)
+            if (tb + G * u < lmax) {
+              float *tl = tile + g * fs + (4 * l16) * TS + tb + G * u;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) tl[i * TS] = v[g][u][i];
+            }
+      }
+    };
+    // (64-branch tiles: 16 step groups x 3 = T <= 48 in one pass; T <= 16 needs one step per group, not two clamped copies more)
+    if (ROWS == 64 && T > G) pass(std::integral_constant<int, 3>{});
+    else pass(std::integral_constant<int, 1>{});
   } else {
     const int bl_in = tid % ROWS, tq = tid / ROWS;    // lanes over branches, the rest over steps
     for (int g = 0; g < 8; ++g) {

@@ -899,23 +899,30 @@ int cmbpo_internal_launch_h3(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
   }
-  // rows per item: the fewest rounds of items x an item's time (measured alone on a CU, AntSafe shapes: 21 / 30 / 51 us at
-  // 32 / 64 / 128 rows -- an item's latency is the step's when the launch is a single round of items).  The full rounds of one
-  // item size may be followed by the leftovers at a SMALLER size in a launch of their own: a last round that would leave
-  // most CUs idle becomes one or two rounds of short items on all of them (100 000 rows x 7 members = 5474 items of 128 rows
-  // on 256 CUs: 21 full rounds + 98 items -> 196 items of 64 rows; 10 000 rows: 2 rounds of 128-row items + 41 items -> 164
-  // of 32 rows, 127 us by this model against 150 for five rounds of 64-row items).  An item is (member, row tile) in
+  // Rows per item: the cheapest plan by a two-number model per item size -- the first round of a launch costs an item's
+  // latency, every further round its steady-state time (tenths of a microsecond, measured by forcing each size over 17 row
+  // counts, profiles/r03/h3_split_plan_sweep.log: 32 / 64 / 128 rows = 22.0 / 31.0 / 55.0 us then 17.5 / 30.0 / 54.0 us per
+  // round at two output tiles; 25.5 / 36.0 / 72.0 then 19.8 / 34.3 / 70.5 at four -- Humanoid's 2 x 46 outputs take two
+  // passes over the output layer, and 64-row items are its better main size).  The full rounds of one item size may be
+  // followed by the leftovers at a SMALLER size in a launch of their own: a last round that would leave most CUs idle
+  // becomes one or two rounds of short items on all of them (100 000 rows x 7 members = 5474 items of 128 rows on 256 CUs:
+  // 21 full rounds + 98 items -> 196 items of 64 rows; 10 000 rows: 2 rounds of 128-row items + 41 items -> 164 of 32 rows,
+  // 135 us by this model -- 134.5 measured -- against 147 for five rounds of 64-row items).  An item is (member, row tile) in
   // member-major order in every list, so a suffix of one list is a suffix of the others; a row's arithmetic does not depend
   // on the item it travels in (tests: bitwise against the forced sizes).
   const int E = m->ensemble;
   static const int split_tail = getenv("CMBPO_ENS_H3_SPLIT_TAIL") ? atoi(getenv("CMBPO_ENS_H3_SPLIT_TAIL")) : 1;
-  static const int split_gap_us = getenv("CMBPO_ENS_H3_SPLIT_GAP") ? atoi(getenv("CMBPO_ENS_H3_SPLIT_GAP")) : 4;   // launch boundary
+  static const int split_gap = getenv("CMBPO_ENS_H3_SPLIT_GAP") ? 10 * atoi(getenv("CMBPO_ENS_H3_SPLIT_GAP")) : 40;   // launch boundary
   int RT = g_h3_rt, RT_tail = 0, full = 0, tail_start = 0;
   if (RT == 0) {
-    const int t_us[3] = {21, 30, 51}, rts[3] = {1, 2, 4};
+    const int first_two[3] = {220, 310, 550}, steady_two[3] = {175, 300, 540};
+    const int first_four[3] = {255, 360, 720}, steady_four[3] = {198, 343, 705};
+    const int *first = m->h3_otp > 2 ? first_four : first_two, *steady = m->h3_otp > 2 ? steady_four : steady_two;
+    const int rts[3] = {1, 2, 4};
+    auto cost_of = [&](int i, long rounds) -> long { return rounds <= 0 ? 0 : first[i] + (rounds - 1) * steady[i]; };
     long best = -1;
     for (int i = 0; i < 3; ++i) {
-      const long cost = (long)cmbpo_ceil_div(cmbpo_ceil_div(a.n_rows, 32 * rts[i]) * E, n_cu) * t_us[i];
+      const long cost = cost_of(i, cmbpo_ceil_div(cmbpo_ceil_div(a.n_rows, 32 * rts[i]) * E, n_cu));
       if (best < 0 || cost <= best) { best = cost; RT = rts[i]; }
     }
     if (split_tail)
@@ -927,7 +934,7 @@ int cmbpo_internal_launch_h3(cmbpo_mlp *m, MlpKernelArgs &a, hipStream_t s) {
         for (int j = 0; j < i; ++j) {
           const int tiles_t = cmbpo_ceil_div(a.n_rows, 32 * rts[j]);
           const int start = e0 * tiles_t + (rts[i] / rts[j]) * t0, n_tail = tiles_t * E - start;
-          const long cost = (long)(fl / n_cu) * t_us[i] + (long)cmbpo_ceil_div(n_tail, n_cu) * t_us[j] + split_gap_us;
+          const long cost = cost_of(i, fl / n_cu) + cost_of(j, cmbpo_ceil_div(n_tail, n_cu)) + split_gap;
           if (cost < best) { best = cost; RT = rts[i]; RT_tail = rts[j]; full = fl; tail_start = start; }
         }
       }

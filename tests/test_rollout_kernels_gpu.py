@@ -78,11 +78,11 @@ def test_ens_forward_f16_item_shapes(hip_lib, rt, task, n):
 
 
 @pytest.mark.parametrize("task,n,forced", [("AntSafe-v2", 35000, 4), ("AntSafe-v2", 10000, 4), ("HalfCheetahSafe-v2", 10000, 2),
-                                           ("AntSafe-v2", 5000, 1), ("AntSafe-v2", 5761, 2), ("HumanoidSafe-v2", 20000, 4)])
+                                           ("AntSafe-v2", 5000, 1), ("AntSafe-v2", 5761, 2), ("HumanoidSafe-v2", 10000, 4)])
 def test_ens_forward_tail_round_as_shorter_items(hip_lib, task, n, forced):
     """The full rounds of one item size followed by the leftovers at a smaller one, in a launch of their own (ens_h3.hip; on
     256 CUs with 7 members: 35 000 and 20 000 rows = 128-row items + a round of 64-row items, 10 000 and 5 000 rows = 128-row
-    items + 32-row items, 5 761 rows = 64-row items + 32-row items).  Every row against the oracle, and bitwise against the
+    items + 32-row items, 5 761 rows and Humanoid shapes at 10 000 rows = 64-row items + 32-row items).  Every row against the oracle, and bitwise against the
     same forward with one item size forced (a single launch, no split)."""
     _cuda()
     rng = np.random.default_rng(4242 + n)

@@ -30,9 +30,11 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int HID = 128;
-constexpr int KGH = HID / 8;    // 16
 constexpr int RS = HID + 4;     // row stride of the [b][n] images (conflict-free ds_write_b128 / ds_read_b32)
 constexpr int RED_LD = BB + 1;
+// row stride of the images at hidden width H (RS / 4 odd; at 256 the split-K reduction image -- 8 waves x 32 x 33 floats -- must
+// still fit one image: 32 x 268)
+__host__ __device__ constexpr int pi_rs(int H) { return H == 128 ? 132 : H + 12; }
 
 enum { MODE_EVAL = 0, MODE_GRAD = 1, MODE_FVP = 2 };
 
@@ -54,6 +56,7 @@ unsigned long long *g_pi_stamps = nullptr;
 struct PiDims {
   int D, A, in_pad, kg0, a_kpad, kga, n_it;  // n_it = row tiles of W0 (1 or 2)
   int oW0, ob0, oW1, ob1, oW2, ob2, ols, P;
+  int H;         // hidden width: 128 (both matrix paths) or 256 (fp32 MFMAs)
 };
 
 struct PiPack {          // device pointers into the handle's blob
@@ -112,7 +115,7 @@ struct PackPlan {
   PackPiece piece[9];
   int total;
   int nb32;      // workgroups of the fp32 part; then one for the maxima, then the f16 images
-  int oW0, nW0, ob0, oW2, nW2;   // the pieces whose largest magnitudes bound dh1 and delta2
+  int oW0, nW0, ob0, nb0, oW2, nW2;   // the pieces whose largest magnitudes bound dh1 and delta2
   H16Img img[5];
   int img_blk[6];                // first workgroup of each image, relative to nb32 + 1
   int n_img;
@@ -161,7 +164,7 @@ __device__ __forceinline__ void pack_max_part(u32x4 *dst16, const float *flat, c
   __shared__ float red[3][256];
   float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
   for (int i = threadIdx.x; i < plan.nW0; i += 256) m0 = fmaxf(m0, fabsf(flat[plan.oW0 + i]));
-  for (int i = threadIdx.x; i < HID; i += 256) m1 = fmaxf(m1, fabsf(flat[plan.ob0 + i]));
+  for (int i = threadIdx.x; i < plan.nb0; i += 256) m1 = fmaxf(m1, fabsf(flat[plan.ob0 + i]));
   for (int i = threadIdx.x; i < plan.nW2; i += 256) m2 = fmaxf(m2, fabsf(flat[plan.oW2 + i]));
   red[0][threadIdx.x] = m0; red[1][threadIdx.x] = m1; red[2][threadIdx.x] = m2;
   __syncthreads();
@@ -209,8 +212,12 @@ __global__ void pack_all_kernel(float *dst, const float *flat, const PackPlan pl
 // Every activation image lives in LDS ONCE, in the row layout [sample][RS] (RS / 4 odd): it is the B operand of
 // the forward / JVP / backward chains (conflict-free 16-B reads, mfma_layer<.., ROWS = true>) and the A / B
 // operand of the weight-gradient MFMAs (conflict-free 4-B reads).  76.8 KB per workgroup -> two per CU.
-template <int MODE, int N_IT>
-__global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
+template <int MODE, int N_IT, int HIDT>
+__global__ __launch_bounds__(2 * HIDT, HIDT == 128 ? 2 : 1) void pi_kernel(const PiArgs p) {
+  // HIDT = the hidden width (128: the shipped policies; 256: configs/baseconfig/base.py's default): a wave per 32 hidden
+  // units, 2 HIDT threads, images of HIDT + pad floats a row
+  constexpr int kThreads = 2 * HIDT, HID = HIDT, KGH = HIDT / 8, RS = pi_rs(HIDT), NW = HIDT / 32;
+  constexpr int AS = kThreads / 32, NITE = 32 / AS;     // element phase: a = tid / 32 + AS it, it < NITE
   extern __shared__ f32x4 smem4[];
   const PiDims d = p.d;
   float *sm = reinterpret_cast<float *>(smem4);
@@ -235,14 +242,14 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
   const bool cached = (MODE == MODE_FVP) && p.cache_r != nullptr;
 
   // persistent accumulators
-  f32x16 gW1[4], gW0[N_IT], gW2;
+  f32x16 gW1[NW], gW0[N_IT], gW2;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) zero(gW1[t]);
+  for (int t = 0; t < NW; ++t) zero(gW1[t]);
 #pragma unroll
   for (int t = 0; t < N_IT; ++t) zero(gW0[t]);
   zero(gW2);
   float gbias = 0.0f;   // thread n < 128: d/d b1[n]; thread 128 + n: d/d b0[n] (column sums of the delta images)
-  float gb2p[4] = {0, 0, 0, 0}, glsp[4] = {0, 0, 0, 0};   // per (a = tid/32 + 8*it) partials over this thread's b
+  float gb2p[NITE] = {}, glsp[NITE] = {};   // per (a = tid/32 + AS*it) partials over this thread's b
   double s_n = 0, s_ra = 0, s_rc = 0, s_kl = 0, s_cost = 0;
 
   // zero the padded cotangent columns (a in [A, 36)) and the padded input columns (k in [D, in_pad)) once: nothing
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int idx = tid + kThreads * i, b = idx >> 5, c = idx & 31;
+        const int idx = tid + kThreads * i, b = idx / (HID / 4), c = idx % (HID / 4);
         reinterpret_cast<f32x4 *>(h1R)[b * (RS / 4) + c] = t1[i];
         reinterpret_cast<f32x4 *>(h2R)[b * (RS / 4) + c] = t2[i];
       }
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
           f32x4 *dst = p.cache_w + (size_t)tile * (2 * IMG4);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const int idx = tid + kThreads * i, b = idx >> 5, c = idx & 31;
+            const int idx = tid + kThreads * i, b = idx / (HID / 4), c = idx % (HID / 4);
             dst[idx] = h1R4[b * (RS / 4) + c];
             dst[IMG4 + idx] = h2R4[b * (RS / 4) + c];
           }
@@ -412,17 +419,16 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
     // ---- element phase over (a, b): this thread owns b = tid & 31, a = tid/32 + 8*it ------------------
     const int eb = tid & 31, er = row0 + eb;
     const bool valid = er < p.n;
-    float z_[4], mu_[4];
+    float z_[NITE], mu_[NITE];
     float logp_part = 0.0f;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int a = (tid >> 5) + 8 * it;
+    for (int it = 0; it < NITE; ++it) {
+      const int a = (tid >> 5) + AS * it;
       z_[it] = mu_[it] = 0.0f;
       if (a < d.A) {
         float m = red[(0 * 32 + a) * RED_LD + eb];
-        m += red[(1 * 32 + a) * RED_LD + eb];
-        m += red[(2 * 32 + a) * RED_LD + eb];
-        m += red[(3 * 32 + a) * RED_LD + eb];
+#pragma unroll
+        for (int wv = 1; wv < NW; ++wv) m += red[(wv * 32 + a) * RED_LD + eb];      // (in wave order)
         if constexpr (MODE == MODE_FVP) {
           m += c_b2[a];
           float cot = 0.0f;
@@ -464,8 +470,8 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
       }
       __syncthreads();   // every thread has read the scratch terms before they are overwritten
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int a = (tid >> 5) + 8 * it;
+      for (int it = 0; it < NITE; ++it) {
+        const int a = (tid >> 5) + AS * it;
         if (a < d.A) {
           if constexpr (MODE == MODE_EVAL) {
             if (valid) {
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
     // dW1 and dW2 need delta2 / the cotangent only (complete since the previous barrier): they run while the slower
     // waves still write delta1
 #pragma unroll
-    for (int J = 0; J < 4; ++J) wgrad_tile(gW1[J], h1R, RS, wave * 32, d2R, RS, J * 32, lane);
+    for (int J = 0; J < NW; ++J) wgrad_tile(gW1[J], h1R, RS, wave * 32, d2R, RS, J * 32, lane);
     wgrad_tile(gW2, h2R, RS, wave * 32, wR, 36, 0, lane);
     __syncthreads();   // delta1 complete
 #pragma unroll
@@ -550,7 +556,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
-      for (int J = 0; J < 4; ++J) part[d.oW1 + (wave * 32 + row) * HID + J * 32 + j] = gW1[J][r];
+      for (int J = 0; J < NW; ++J) part[d.oW1 + (wave * 32 + row) * HID + J * 32 + j] = gW1[J][r];
 #pragma unroll
       for (int t = 0; t < N_IT; ++t)
         if (32 * t + row < d.D) part[d.oW0 + (32 * t + row) * HID + wave * 32 + j] = gW0[t][r];
@@ -558,8 +564,8 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
     }
     part[(tid < HID ? d.ob1 : d.ob0) + (tid & (HID - 1))] = gbias;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int a = (tid >> 5) + 8 * it;
+    for (int it = 0; it < NITE; ++it) {
+      const int a = (tid >> 5) + AS * it;
       const float sb = half_sum(gb2p[it]), sl = half_sum(glsp[it]);
       if (a < d.A && (tid & 31) == 0) {
         part[d.ob2 + a] = sb;
@@ -570,7 +576,7 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
   }
   if constexpr (MODE != MODE_FVP) {
     // tid < 32 hold the per-sample sums; s_kl is spread over every thread
-    __shared__ double sd[4];
+    __shared__ double sd[NW];
     const double kl = wave_sum_d(s_kl);
     if (lane == 0) sd[wave] = kl;
     __syncthreads();
@@ -580,7 +586,10 @@ __global__ __launch_bounds__(kThreads, 2) void pi_kernel(const PiArgs p) {
         atomicAdd(&p.sums[0], n);
         atomicAdd(&p.sums[1], ra);
         atomicAdd(&p.sums[2], rc);
-        atomicAdd(&p.sums[3], sd[0] + sd[1] + sd[2] + sd[3]);
+        double klt = sd[0];
+#pragma unroll
+        for (int wv = 1; wv < NW; ++wv) klt += sd[wv];
+        atomicAdd(&p.sums[3], klt);
         atomicAdd(&p.sums[4], c);
       }
     }
@@ -780,19 +789,20 @@ int do_pack(const cmbpo_pi *h, float *dst, const float *flat, hipStream_t s) {
     total += count;
   };
   // forward packs: A[i = out unit][k = in unit] = W[k][i]
-  add(h->off_F0, d.oW0, HID, d.D, 1, HID, d.kg0, 4 * d.kg0 * 256);
-  add(h->off_F1, d.oW1, HID, HID, 1, HID, KGH, 4 * KGH * 256);
-  add(h->off_F2, d.oW2, d.A, HID, 1, d.A, KGH, KGH * 256);
+  const int H = d.H, NT = H / 32, KH = H / 8;
+  add(h->off_F0, d.oW0, H, d.D, 1, H, d.kg0, NT * d.kg0 * 256);
+  add(h->off_F1, d.oW1, H, H, 1, H, KH, NT * KH * 256);
+  add(h->off_F2, d.oW2, d.A, H, 1, d.A, KH, KH * 256);
   // backward packs: A[i = in unit][k = out unit] = W[i][k]
-  add(h->off_B1, d.oW1, HID, HID, HID, 1, KGH, 4 * KGH * 256);
-  add(h->off_B2, d.oW2, HID, d.A, d.A, 1, d.kga, 4 * d.kga * 256);
-  add(h->off_b0, d.ob0, HID, 0, 0, 0, 0, HID);
-  add(h->off_b1, d.ob1, HID, 0, 0, 0, 0, HID);
+  add(h->off_B1, d.oW1, H, H, H, 1, KH, NT * KH * 256);
+  add(h->off_B2, d.oW2, H, d.A, d.A, 1, d.kga, NT * d.kga * 256);
+  add(h->off_b0, d.ob0, H, 0, 0, 0, 0, H);
+  add(h->off_b1, d.ob1, H, 0, 0, 0, 0, H);
   add(h->off_b2, d.ob2, d.A, 0, 0, 0, 0, 32);
   add(h->off_ls, d.ols, d.A, 0, 0, 0, 0, 32);
   plan.total = total;
   plan.nb32 = cmbpo_ceil_div(total, 256);
-  plan.oW0 = d.oW0; plan.nW0 = d.D * HID; plan.ob0 = d.ob0; plan.oW2 = d.oW2; plan.nW2 = HID * d.A;
+  plan.oW0 = d.oW0; plan.nW0 = d.D * H; plan.ob0 = d.ob0; plan.nb0 = H; plan.oW2 = d.oW2; plan.nW2 = H * d.A;
   // f16 images: the direction pack needs the forward ones only
   const bool params = dst == h->blob;
   const int s0 = 2 * d.n_it;
@@ -802,10 +812,12 @@ int do_pack(const cmbpo_pi *h, float *dst, const float *flat, hipStream_t s) {
     plan.img_blk[ni++] = blk;
     blk += cmbpo_ceil_div(n_tiles * slabs * 64, 256);
   };
+  if (H == HID) {      // (the f16 kernels are written for 128 hidden units: a 256-wide policy runs the fp32 MFMAs)
   add16(d.oW0, 1, HID, HID, d.D, 4, s0, H16_F0, L_F0);          // A[unit][input] = W0[input][unit]
   add16(d.oW1, 1, HID, HID, HID, 4, 8, H16_F1, L_F1);           // A[unit][k] = W1[k][unit]
   add16(d.oW2, 1, d.A, d.A, HID, 1, 8, H16_F2, L_F2);           // A[action][k] = W2[k][action]
-  if (params) {
+  }
+  if (params && H == HID) {
     add16(d.oW1, HID, 1, HID, HID, 4, 8, H16_B1, L_B1);         // A[unit][k] = W1[unit][k]
     add16(d.oW2, d.A, 1, HID, d.A, 4, 2, H16_B2, L_B2);         // A[unit][action] = W2[unit][action]
   }
@@ -818,7 +830,7 @@ int do_pack(const cmbpo_pi *h, float *dst, const float *flat, hipStream_t s) {
 }
 
 size_t lds_bytes(const PiDims &d, bool f16) {
-  const size_t f = (size_t)BB * ((f16 ? 32 * d.n_it : d.in_pad) + 4) + 4 * BB * RS + BB * 36;
+  const size_t f = (size_t)BB * ((f16 ? 32 * d.n_it : d.in_pad) + 4) + 4 * BB * pi_rs(d.H) + BB * 36;
   return f * sizeof(float);
 }
 
@@ -831,10 +843,10 @@ int launch_pi_k(cmbpo_pi *h, PiArgs &a, hipStream_t s, KERN kern, size_t &attr_b
     attr_bytes = lds;
   }
   const int tiles = cmbpo_ceil_div(a.n, BB);
-  const int resident = 2 * h->n_cu;   // two 76.8 KB workgroups per CU
+  const int resident = (h->d.H == HID ? 2 : 1) * h->n_cu;   // two 76.8 KB workgroups per CU (one of 150 KB at 256 hidden units)
   const int grid = tiles < resident ? tiles : resident;
   a.part = h->parts; a.part_ld = h->part_ld;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * h->d.H), lds, s, a);
   h->last_grid = grid;
   if (reduce && a.vec != nullptr)
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(cmbpo_ceil_div(h->d.P, 64)), dim3(1024), 0, s, h->parts, h->part_ld, grid,
@@ -845,8 +857,9 @@ int launch_pi_k(cmbpo_pi *h, PiArgs &a, hipStream_t s, KERN kern, size_t &attr_b
 
 template <int MODE, int N_IT>
 int launch_pi_n(cmbpo_pi *h, PiArgs &a, hipStream_t s) {
-  static size_t attr[3] = {0, 0, 0};   // per kernel: the dynamic LDS already granted
-  if (pi_path() == 0) return launch_pi_k(h, a, s, pi_kernel<MODE, N_IT>, attr[0], false, MODE != MODE_EVAL);
+  static size_t attr[4] = {0, 0, 0, 0};   // per kernel: the dynamic LDS already granted
+  if (h->d.H == 256) return launch_pi_k(h, a, s, pi_kernel<MODE, N_IT, 256>, attr[3], false, MODE != MODE_EVAL);
+  if (pi_path() == 0) return launch_pi_k(h, a, s, pi_kernel<MODE, N_IT, 128>, attr[0], false, MODE != MODE_EVAL);
   if (MODE == MODE_FVP && a.cache_r != nullptr)
     return launch_pi_k(h, a, s, pi_kernel_h<MODE, N_IT, true>, attr[1], true, MODE != MODE_EVAL);
   return launch_pi_k(h, a, s, pi_kernel_h<MODE, N_IT, false>, attr[2], true, MODE != MODE_EVAL);
@@ -882,7 +895,7 @@ int fill_args(cmbpo_pi *h, const cmbpo_pi_batch_t *b, PiArgs &a, const char *who
 // the saved activations a Fisher-vector product on batch b may read, or NULL
 const f32x4 *act_for(const cmbpo_pi *h, const cmbpo_pi_batch_t *b) {
   if (!h->act_keep || !h->act_valid || h->act == nullptr || b->obs != h->act_obs || b->n != h->act_n ||
-      h->act_path != pi_path())      // (the two matrix paths keep different images)
+      h->act_path != (h->d.H == HID ? pi_path() : 0))      // (the two matrix paths keep different images)
     return nullptr;
   return reinterpret_cast<const f32x4 *>(h->act);
 }
@@ -896,7 +909,7 @@ bool act_reserve(cmbpo_pi *h, int n) {
   h->act = nullptr; h->act_tiles = 0;
   // (per tile: the fp32 kernels keep two dense [32][128] images, the f16 kernels the padded LDS block -- room for the larger,
   //  plus a KiB: the last LDS-DMA piece of a block reads past its end)
-  if (hipMalloc(reinterpret_cast<void **>(&h->act), tiles * 2 * BB * RS * sizeof(float) + 1024) != hipSuccess) {
+  if (hipMalloc(reinterpret_cast<void **>(&h->act), tiles * 2 * BB * pi_rs(h->d.H) * sizeof(float) + 1024) != hipSuccess) {
     (void)hipGetLastError();
     h->act = nullptr;
     return false;
@@ -909,7 +922,7 @@ bool act_reserve(cmbpo_pi *h, int n) {
 
 extern "C" int cmbpo_pi_create(cmbpo_pi_t **out, int obs_dim, int hidden, int act_dim) {
   CMBPO_REQUIRE(out != nullptr, "cmbpo_pi_create: out is NULL");
-  CMBPO_REQUIRE(hidden == HID, "cmbpo_pi_create: hidden must be 128 (got %d)", hidden);
+  CMBPO_REQUIRE(hidden == HID || hidden == 256, "cmbpo_pi_create: hidden must be 128 or 256 (got %d)", hidden);
   CMBPO_REQUIRE(obs_dim >= 1 && obs_dim <= 64, "cmbpo_pi_create: obs_dim %d not in [1, 64]", obs_dim);
   CMBPO_REQUIRE(act_dim >= 1 && act_dim <= 32, "cmbpo_pi_create: act_dim %d not in [1, 32]", act_dim);
   cmbpo_pi *h = new (std::nothrow) cmbpo_pi();
@@ -919,13 +932,15 @@ extern "C" int cmbpo_pi_create(cmbpo_pi_t **out, int obs_dim, int hidden, int ac
   d.in_pad = (obs_dim + 7) / 8 * 8; d.kg0 = d.in_pad / 8;
   d.a_kpad = (act_dim + 7) / 8 * 8; d.kga = d.a_kpad / 8;
   d.n_it = (obs_dim + 31) / 32;
-  d.oW0 = 0; d.ob0 = obs_dim * HID; d.oW1 = d.ob0 + HID; d.ob1 = d.oW1 + HID * HID; d.oW2 = d.ob1 + HID;
-  d.ob2 = d.oW2 + HID * act_dim; d.ols = d.ob2 + act_dim; d.P = d.ols + act_dim;
+  d.H = hidden;
+  const int H = hidden, NT = H / 32, KH = H / 8;
+  d.oW0 = 0; d.ob0 = obs_dim * H; d.oW1 = d.ob0 + H; d.ob1 = d.oW1 + H * H; d.oW2 = d.ob1 + H;
+  d.ob2 = d.oW2 + H * act_dim; d.ols = d.ob2 + act_dim; d.P = d.ols + act_dim;
   size_t off = 0;
   auto take = [&](size_t n) { size_t o = off; off += (n + 3) / 4 * 4; return o; };
-  h->off_F0 = take((size_t)4 * d.kg0 * 256); h->off_F1 = take((size_t)4 * KGH * 256); h->off_F2 = take((size_t)KGH * 256);
-  h->off_B1 = take((size_t)4 * KGH * 256); h->off_B2 = take((size_t)4 * d.kga * 256);
-  h->off_b0 = take(HID); h->off_b1 = take(HID); h->off_b2 = take(32); h->off_ls = take(32);
+  h->off_F0 = take((size_t)NT * d.kg0 * 256); h->off_F1 = take((size_t)NT * KH * 256); h->off_F2 = take((size_t)KH * 256);
+  h->off_B1 = take((size_t)NT * KH * 256); h->off_B2 = take((size_t)NT * d.kga * 256);
+  h->off_b0 = take(H); h->off_b1 = take(H); h->off_b2 = take(32); h->off_ls = take(32);
   h->pack_floats = off;
   h->has_params = false;
   h->act = nullptr; h->act_tiles = 0; h->act_keep = false; h->act_valid = false; h->act_obs = nullptr; h->act_n = 0; h->act_hits = 0;
@@ -1006,7 +1021,7 @@ extern "C" int cmbpo_pi_loss_grad(cmbpo_pi_t *h, const cmbpo_pi_batch_t *b, int 
   const bool save = h->act_keep && act_for(h, b) == nullptr && act_reserve(h, b->n);
   if (save) a.cache_w = reinterpret_cast<f32x4 *>(h->act);
   if (int rc = launch_pi<MODE_GRAD>(h, a, s)) return rc;
-  if (save) { h->act_valid = true; h->act_obs = b->obs; h->act_n = b->n; h->act_path = pi_path(); }
+  if (save) { h->act_valid = true; h->act_obs = b->obs; h->act_n = b->n; h->act_path = h->d.H == HID ? pi_path() : 0; }
   return CMBPO_OK;
 }
 

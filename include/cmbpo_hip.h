@@ -338,8 +338,11 @@ int cmbpo_buffer_flatten(const cmbpo_rollout_t *r, const int32_t *d_offsets,
  * SUMS over the samples of this call (the caller divides by the global sample
  * count after an all-reduce, instead of mpi_avg's equal-shard assumption,
  * utilities/mpi_tools.py:67-69).  Parameter vectors are flat float32[P] in the
- * order of get_vars('pi') (network/ac_network.py:35-36): W0[obs,128], b0,
- * W1[128,128], b1, W2[128,act], b2, log_std.
+ * order of get_vars('pi') (network/ac_network.py:35-36): W0[obs,H], b0,
+ * W1[H,H], b1, W2[H,act], b2, log_std.  Hidden width H: 128 (every shipped
+ * experiment; both matrix paths) or 256 (configs/baseconfig/base.py:7, the
+ * default: fp32 MFMAs whatever cmbpo_set_pi_matrix_path says); obs <= 64,
+ * act <= 32.
  * ------------------------------------------------------------------------ */
 typedef struct cmbpo_pi cmbpo_pi_t;
 

@@ -40,24 +40,29 @@ def _close(got, ref, rtol=1e-3, arel=3e-5, msg=""):
     np.testing.assert_allclose(got, ref, rtol=rtol, atol=arel * float(np.max(np.abs(ref))) + 1e-12, err_msg=msg)
 
 
-def _setup(D, A, n, seed, cost_p=0.3, cadv_scale=1.0, T=35):
+def _setup(D, A, n, seed, cost_p=0.3, cadv_scale=1.0, T=35, hidden=128):
     from worlds import make_update_batch
     from cmbpo_amd.cpo_update import PolicyOps
     rng = np.random.default_rng(seed)
-    params, batch = make_update_batch(rng, n, D, A, 128, cost_p, cadv_scale, T)
+    params, batch = make_update_batch(rng, n, D, A, hidden, cost_p, cadv_scale, T)
     # move off theta_old a little so ratio != 1 and KL != 0 are exercised too
-    graph = refupdate.PolicyGraph(D, A, batch, max_path_length=T, hidden=128)
-    ops = PolicyOps(D, A, 128, device="cuda:0")
+    graph = refupdate.PolicyGraph(D, A, batch, max_path_length=T, hidden=hidden)
+    ops = PolicyOps(D, A, hidden, device="cuda:0")
     ops.set_params(params)
     ops.bind(batch["obs"], batch["act"], batch["adv"], batch["cadv"], batch["logp_old"], batch["cost"],
              batch["mu_old"], batch["log_std_old"])
     return rng, params, batch, graph, ops
 
 
-@pytest.mark.parametrize("D,A,n", [(29, 8, 1037), (20, 6, 64), (47, 17, 500), (21, 3, 31), (64, 32, 257), (3, 1, 100)])
-def test_loss_grad_fvp_eval_match_oracle(hip_lib, D, A, n):
+@pytest.mark.parametrize("D,A,n,hidden", [(29, 8, 1037, 128), (20, 6, 64, 128), (47, 17, 500, 128), (21, 3, 31, 128),
+                                          (64, 32, 257, 128), (3, 1, 100, 128),
+                                          # configs/baseconfig/base.py:7: the default policy width (fp32 MFMAs on either path)
+                                          (29, 8, 1037, 256), (47, 17, 300, 256), (3, 1, 33, 256)])
+def test_loss_grad_fvp_eval_match_oracle(hip_lib, pi_path, D, A, n, hidden):
     _need_gpu()
-    rng, params, batch, graph, ops = _setup(D, A, n, seed=D * 100 + A)
+    if hidden == 256 and pi_path == 1:
+        pytest.skip("one kernel set at width 256: covered under the fp32mfma id")
+    rng, params, batch, graph, ops = _setup(D, A, n, seed=D * 100 + A, hidden=hidden)
     for shift in (0.0, 0.03):
         p = (params + shift * rng.standard_normal(params.shape)).astype(np.float32)
         ops.set_params(p)
@@ -164,20 +169,23 @@ SCENARIOS = [   # name, cost_p, cadv_scale, cost_lim, constrained, real_cost, se
 ]
 
 
+@pytest.mark.parametrize("hidden", [128, 256])
 @pytest.mark.parametrize("name,cost_p,cadv_scale,cost_lim,constrained,real_cost,seed", SCENARIOS)
-def test_update_policy_matches_oracle(hip_lib, name, cost_p, cadv_scale, cost_lim, constrained, real_cost, seed):
+def test_update_policy_matches_oracle(hip_lib, pi_path, name, cost_p, cadv_scale, cost_lim, constrained, real_cost, seed, hidden):
     _need_gpu()
+    if hidden == 256 and (pi_path == 1 or name not in ("feasible", "violating")):
+        pytest.skip("width 256: one kernel set, two scenarios")
     from worlds import make_update_batch
     from cmbpo_amd.cpo_policy import CPOPolicy
     D, A, n, T = 29, 8, 4000, 35
     rng = np.random.default_rng(seed)
-    params, batch = make_update_batch(rng, n, D, A, 128, cost_p, cadv_scale, T)
+    params, batch = make_update_batch(rng, n, D, A, hidden, cost_p, cadv_scale, T)
 
     class _Space:
         def __init__(self, d):
             self.shape = (d,)
 
-    pol = CPOPolicy(_Space(D), _Space(A), a_hidden_layer_sizes=(128, 128), vf_hidden_layer_sizes=(128, 128),
+    pol = CPOPolicy(_Space(D), _Space(A), a_hidden_layer_sizes=(hidden, hidden), vf_hidden_layer_sizes=(128, 128),
                     vf_ensemble_size=3, vf_elites=2, vf_activation="swish", vf_loss="MSE", device="cuda:0",
                     constrain_cost=constrained, cost_lim=cost_lim, target_kl=0.01, max_path_length=T)
     pol.set_params(params)
@@ -188,7 +196,7 @@ def test_update_policy_matches_oracle(hip_lib, name, cost_p, cadv_scale, cost_li
     info = pol.update_policy(buf)
     new_params = pol.actor.get_flat_params()
 
-    graph = refupdate.PolicyGraph(D, A, batch, max_path_length=T, hidden=128)
+    graph = refupdate.PolicyGraph(D, A, batch, max_path_length=T, hidden=hidden)
     agent = refupdate.AgentState(T, constrained=constrained)
 
     def grads():
@@ -245,14 +253,14 @@ def test_cg_solve_graph_matches_eager_loop(hip_lib):
         _close(outs[0], ref, rtol=2e-2, arel=2e-3)
 
 
-@pytest.mark.parametrize("D,A,n", [(29, 8, 5003), (47, 17, 500), (21, 3, 31)])
-def test_fvp_from_saved_activations_is_bit_identical(hip_lib, D, A, n):
+@pytest.mark.parametrize("D,A,n,hidden", [(29, 8, 5003, 128), (47, 17, 500, 128), (21, 3, 31, 128), (29, 8, 2000, 256)])
+def test_fvp_from_saved_activations_is_bit_identical(hip_lib, D, A, n, hidden):
     """cmbpo_pi_keep_activations: the Fisher-vector products that read the hidden activations cmbpo_pi_loss_grad saved
     == the ones that recompute the forward chain, bit for bit (eager products and the whole CG solve); the saved
     images are dropped with the parameters they belong to."""
     _need_gpu()
     from cmbpo_amd import _lib
-    rng, params, batch, graph, ops = _setup(D, A, n, seed=7 * D + A)
+    rng, params, batch, graph, ops = _setup(D, A, n, seed=7 * D + A, hidden=hidden)
     uses = lambda: _lib.lib().cmbpo_pi_saved_activation_uses(ops._h)
     v = rng.standard_normal(params.shape).astype(np.float32)
     b = torch.from_numpy(rng.standard_normal(params.shape).astype(np.float32)).cuda()

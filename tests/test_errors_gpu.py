@@ -69,7 +69,7 @@ def test_rollout_and_update_argument_checks(hip_lib):
         assert getattr(lib, fn)(C.byref(rs), None) < 0, fn
         assert len(lib.cmbpo_last_error()) > 10
     h = C.c_void_p()
-    assert lib.cmbpo_pi_create(C.byref(h), 29, 64, 8) == -1      # hidden must be 128
+    assert lib.cmbpo_pi_create(C.byref(h), 29, 64, 8) == -1      # hidden must be 128 or 256
     assert lib.cmbpo_pi_create(C.byref(h), 100, 128, 8) == -1    # obs_dim > 64
     assert lib.cmbpo_pi_create(C.byref(h), 29, 128, 8) == 0
     b = _lib.PiBatchStruct()

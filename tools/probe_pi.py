@@ -1,5 +1,5 @@
 """Perf / agreement probe of the policy kernels (loss_grad, Fisher-vector product, eval) on the two matrix paths (dev tool).
-usage: probe_pi.py [N] [D] [A]"""
+usage: probe_pi.py [N] [D] [A] [hidden]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
@@ -12,15 +12,16 @@ from worlds import make_update_batch
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 3_400_000
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 29
 A = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+H = int(sys.argv[4]) if len(sys.argv) > 4 else 128      # 256: one kernel set (fp32 MFMAs) whatever the path
 rng = np.random.default_rng(0)
-params, batch = make_update_batch(rng, N, D, A, 128, 0.3, 1.0, 35)
+params, batch = make_update_batch(rng, N, D, A, H, 0.3, 1.0, 35)
 L = _lib.lib()
 v = rng.standard_normal(params.shape).astype(np.float32)
 res = {}
 for path in (0, 1):
     L.cmbpo_set_pi_matrix_path(path)
     for keep in (False, True):
-        ops = PolicyOps(D, A, 128, device="cuda:0")
+        ops = PolicyOps(D, A, H, device="cuda:0")
         ops.keep_activations = keep
         ops.set_params(params)
         ops.bind(batch["obs"], batch["act"], batch["adv"], batch["cadv"], batch["logp_old"], batch["cost"],

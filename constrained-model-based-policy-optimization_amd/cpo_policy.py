@@ -160,18 +160,18 @@ class CPOPolicy:
         """cpo_policy.py:600-656: pre-measures, CPOAgent.update_pi, post-measures and deltas."""
         self._sync_ops()
         self._bind(buf_inputs)
-        cost = buf_inputs[9]
-        cur_cost = (float(cost.mean()) if isinstance(cost, torch.Tensor) else float(np.mean(cost))) * self.max_path_length
-        if cur_cost - self.cost_lim > 0 and self.agent.cares_about_cost:
-            self.logger.log('Warning! Safety constraint is already violated.', 'red')
         info = self.agent.update_pi(self.ops, self.target_kl, self.cost_lim, self.real_c_buffer)
+        # (the batch's mean cost comes out of the update's own loss kernel -- the same sum, over every rank's samples --
+        # instead of a reduction and a blocking read of their own in front of it)
+        if float(info["cur_cret_avg"]) - self.cost_lim > 0 and self.agent.cares_about_cost:
+            self.logger.log('Warning! Safety constraint is already violated.', 'red')
         # pre / post measures come out of the update's own kernels (the reference spends two extra
         # sess.run calls on them, cpo_policy.py:613-618,647-656)
         pre, post = info["pre"], info["post"]
         self.logger.store(LossPi=pre["LossPi"], SurrCost=pre["SurrCost"], SurrAdv=pre["SurrAdv"],
                           Entropy=pre["Entropy"])
         # the accepted (or restored) parameters now live in ops; mirror them into the rollout actor
-        self.actor.set_params(self.ops.get_params())
+        self.actor.set_params(info["params"] if info.get("params") is not None else self.ops.get_params())
         self._ops_version = self.actor.version
         deltas = {k + "Delta": post[k] - pre[k] for k in ("LossPi", "SurrCost", "SurrAdv")}
         self.logger.store(KL=post["KL"], **deltas)

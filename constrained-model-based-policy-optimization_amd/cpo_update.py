@@ -96,6 +96,36 @@ class PolicyOps:
     def _s(self):
         return _lib.current_stream()
 
+    def early_read(self, *tensors, tag=""):
+        """Start copying small device results to the host behind everything enqueued on the current stream SO FAR -- on a
+        side stream, so that the copy does not queue behind what the caller enqueues next (a CG solve of a millisecond) --
+        and return a function that waits for the copies and yields them as NumPy arrays.  The host then decides the next
+        step while the GPU is still busy, instead of the GPU idling through three blocking copies and the decision.
+        Reads with the same `tag` share their pinned host buffers: take one's result before starting the next."""
+        with torch.cuda.device(self.device):
+            if getattr(self, "_rd_stream", None) is None:
+                self._rd_stream = torch.cuda.Stream(device=self.device)
+                self._rd_pinned = {}
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._rd_stream.wait_event(ev)
+            hosts = []
+            with torch.cuda.stream(self._rd_stream):
+                for k, t in enumerate(tensors):
+                    key = (tag, k, t.dtype, tuple(t.shape))
+                    h = self._rd_pinned.get(key)
+                    if h is None:
+                        h = self._rd_pinned[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                    h.copy_(t, non_blocking=True)
+                    hosts.append(h)
+                done = torch.cuda.Event()
+                done.record(self._rd_stream)
+
+        def wait():
+            done.synchronize()
+            return [h.numpy().copy() for h in hosts]
+        return wait
+
     # -- parameters ----------------------------------------------------------------------------------------
     def set_params(self, flat):
         """flat: NumPy / torch vector [P] (host or device)."""
@@ -265,10 +295,12 @@ class CPOAgent:
             if self.ent_reg:
                 g[-A:] -= float(self.ent_reg)                       # d(-ent_reg * ent) / d log_std
             ops.dots([(b, b)], offset=9)
-            v = ops.cg_dev(g, wk["v"], damping)                      # :210 (enqueued before the first sync)
-            sg = ops.sums_g.cpu().numpy()                             # <- host synchronisation #0: losses, b.b
-            bb = F32(ops.scal[9].item())
-            log_std = ops.params[-A:].cpu().numpy()
+            rd0 = ops.early_read(ops.sums_g, ops.scal[9:10], ops.params[-A:], tag="pre")   # (nothing enqueued below writes these)
+            v = ops.cg_dev(g, wk["v"], damping)                      # :210 (enqueued before the first host wait)
+            # host wait #0 -- losses, b.b, log_std: they arrive while the first CG solve runs, and the second solve is
+            # enqueued behind it before it ends
+            sg, bb_, log_std = rd0()
+            bb = F32(bb_[0])
         n = sg[0]
         ent = self._ent(log_std)
         surr_adv_old = sg[1] / n
@@ -344,15 +376,22 @@ class CPOAgent:
                 ops.lincomb(x, inv, wk["v"], inv * float(nu), wk["w"])
             else:
                 ops.lincomb(x, float(nu), wk["w"])
+            rd_x = ops.early_read(x, tag="step")                      # the step, for the diagnostics (x is only read below)
         info = dict(Optim_A=A_, Optim_B=B_, Optim_c=c, Optim_q=q, Optim_r=r, Optim_s=s, Optim_Lam=lam,
                     Optim_Nu=nu, Penalty=nu, PenaltyDelta=0, Margin=self.margin, OptimCase=optim_case)
         self.logger.store(**info)
 
+        trial = {}
+
         def set_and_eval(step):                                     # :278-280
             with torch.cuda.device(ops.device):
                 ops.lincomb(ops.params, 1.0, wk["old"], -float(step), x)
+                # (the trial parameters travel to the host beside the evaluation: the caller mirrors the accepted ones
+                # into the rollout actor without a blocking copy of its own)
+                trial["params"] = ops.early_read(ops.params, tag="trial")
                 ops.set_params(ops.params)
                 sm = ops.eval_dev(ops.sums).cpu().numpy()           # <- host synchronisation per trial
+                trial["params"] = trial["params"]()[0]
                 ls = ops.params[-A:].cpu().numpy() if self.ent_reg else log_std
             nn = sm[0]
             ent_new = self._ent(ls)
@@ -374,7 +413,9 @@ class CPOAgent:
                 info["BacktrackIters"] = j
                 kl, pi_l_new, surr_cost_new, ent_new = set_and_eval(step=0.)
         info["accepted"] = accepted
-        info["step"] = x.cpu().numpy()
+        info["step"] = rd_x()[0]
+        info["cur_cret_avg"] = cur_cret_avg
+        info["params"] = trial.get("params")                        # the parameters ops holds now (accepted or restored)
         info["pre"] = pre
         info["post"] = dict(LossPi=pi_l_new, SurrCost=surr_cost_new, KL=kl, Entropy=F32(ent_new),
                             SurrAdv=F32(-float(pi_l_new) - self.ent_reg * ent_new))

@@ -376,7 +376,6 @@ class CPOAgent:
                 ops.lincomb(x, inv, wk["v"], inv * float(nu), wk["w"])
             else:
                 ops.lincomb(x, float(nu), wk["w"])
-            rd_x = ops.early_read(x, tag="step")                      # the step, for the diagnostics (x is only read below)
         info = dict(Optim_A=A_, Optim_B=B_, Optim_c=c, Optim_q=q, Optim_r=r, Optim_s=s, Optim_Lam=lam,
                     Optim_Nu=nu, Penalty=nu, PenaltyDelta=0, Margin=self.margin, OptimCase=optim_case)
         self.logger.store(**info)
@@ -386,13 +385,18 @@ class CPOAgent:
         def set_and_eval(step):                                     # :278-280
             with torch.cuda.device(ops.device):
                 ops.lincomb(ops.params, 1.0, wk["old"], -float(step), x)
-                # (the trial parameters travel to the host beside the evaluation: the caller mirrors the accepted ones
-                # into the rollout actor without a blocking copy of its own)
-                trial["params"] = ops.early_read(ops.params, tag="trial")
                 ops.set_params(ops.params)
-                sm = ops.eval_dev(ops.sums).cpu().numpy()           # <- host synchronisation per trial
-                trial["params"] = trial["params"]()[0]
-                ls = ops.params[-A:].cpu().numpy() if self.ent_reg else log_std
+                ops.eval_dev(ops.sums)
+                # (the trial parameters -- and once the step, for the diagnostics -- travel to the host while the evaluation
+                # runs: starting a read costs the host ~40 us, which the GPU must not spend idle; the caller mirrors the
+                # accepted parameters into the rollout actor without a blocking copy of its own)
+                rd = ops.early_read(ops.params, tag="trial") if "step" in trial else ops.early_read(ops.params, x, tag="trial")
+                sm = ops.sums.cpu().numpy()                         # <- host synchronisation per trial
+                got = rd()
+                trial["params"] = got[0]
+                if len(got) > 1:
+                    trial["step"] = got[1]
+                ls = got[0][-A:] if self.ent_reg else log_std
             nn = sm[0]
             ent_new = self._ent(ls)
             return F32(sm[3] / nn), F32(-(sm[1] / nn + self.ent_reg * ent_new)), F32(sm[2] / nn), ent_new
@@ -413,7 +417,7 @@ class CPOAgent:
                 info["BacktrackIters"] = j
                 kl, pi_l_new, surr_cost_new, ent_new = set_and_eval(step=0.)
         info["accepted"] = accepted
-        info["step"] = rd_x()[0]
+        info["step"] = trial["step"] if "step" in trial else x.cpu().numpy()
         info["cur_cret_avg"] = cur_cret_avg
         info["params"] = trial.get("params")                        # the parameters ops holds now (accepted or restored)
         info["pre"] = pre

@@ -58,10 +58,8 @@ def _setup(D, A, n, seed, cost_p=0.3, cadv_scale=1.0, T=35, hidden=128):
                                           (64, 32, 257, 128), (3, 1, 100, 128),
                                           # configs/baseconfig/base.py:7: the default policy width (fp32 MFMAs on either path)
                                           (29, 8, 1037, 256), (47, 17, 300, 256), (3, 1, 33, 256)])
-def test_loss_grad_fvp_eval_match_oracle(hip_lib, pi_path, D, A, n, hidden):
+def test_loss_grad_fvp_eval_match_oracle(hip_lib, D, A, n, hidden):
     _need_gpu()
-    if hidden == 256 and pi_path == 1:
-        pytest.skip("one kernel set at width 256: covered under the fp32mfma id")
     rng, params, batch, graph, ops = _setup(D, A, n, seed=D * 100 + A, hidden=hidden)
     for shift in (0.0, 0.03):
         p = (params + shift * rng.standard_normal(params.shape)).astype(np.float32)
@@ -169,12 +167,10 @@ SCENARIOS = [   # name, cost_p, cadv_scale, cost_lim, constrained, real_cost, se
 ]
 
 
-@pytest.mark.parametrize("hidden", [128, 256])
-@pytest.mark.parametrize("name,cost_p,cadv_scale,cost_lim,constrained,real_cost,seed", SCENARIOS)
-def test_update_policy_matches_oracle(hip_lib, pi_path, name, cost_p, cadv_scale, cost_lim, constrained, real_cost, seed, hidden):
+@pytest.mark.parametrize("name,cost_p,cadv_scale,cost_lim,constrained,real_cost,seed,hidden",
+                         [sc + (128,) for sc in SCENARIOS] + [sc + (256,) for sc in SCENARIOS[:2]])
+def test_update_policy_matches_oracle(hip_lib, name, cost_p, cadv_scale, cost_lim, constrained, real_cost, seed, hidden):
     _need_gpu()
-    if hidden == 256 and (pi_path == 1 or name not in ("feasible", "violating")):
-        pytest.skip("width 256: one kernel set, two scenarios")
     from worlds import make_update_batch
     from cmbpo_amd.cpo_policy import CPOPolicy
     D, A, n, T = 29, 8, 4000, 35

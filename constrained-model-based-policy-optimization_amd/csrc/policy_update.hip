@@ -609,7 +609,15 @@ __global__ __launch_bounds__(1024) void reduce_parts_kernel(const float *part, i
   const int i = blockIdx.x * 64 + c;
   float s = 0.0f;
   if (i < P)
-    for (int w = g; w < n_parts; w += 16) s += part[(size_t)w * part_ld + i];
+    // (eight partials in flight per thread, added in the order of the plain loop: same bits)
+    for (int w = g; w < n_parts; w += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = (w + 16 * k < n_parts) ? part[(size_t)(w + 16 * k) * part_ld + i] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (w + 16 * k < n_parts) s += v[k];
+    }
   sm[g][c] = s;
   __syncthreads();
   if (g == 0 && i < P) {
@@ -658,7 +666,15 @@ __global__ __launch_bounds__(1024) void cg_k1_kernel(const float *part, int part
   }
   float s = 0.0f;
   if (i < P)
-    for (int w = g; w < n_parts; w += 16) s += part[(size_t)w * part_ld + i];
+    // (eight partials in flight per thread, added in the order of the plain loop: same bits)
+    for (int w = g; w < n_parts; w += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = (w + 16 * k < n_parts) ? part[(size_t)(w + 16 * k) * part_ld + i] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (w + 16 * k < n_parts) s += v[k];
+    }
   sm[g][c] = s;
   __syncthreads();
   double pz = 0.0;

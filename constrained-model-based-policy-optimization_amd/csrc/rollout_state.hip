@@ -919,7 +919,13 @@ __global__ __launch_bounds__(256) void get_pass2_kernel(const cmbpo_rollout_t r,
 // through LDS ([branch][step][dim]) and writes each branch's samples as one run -- the runs of a tile are adjacent, the
 // tile's output is a single contiguous block.  (Reading the output order straight from the buffers touched a 116-byte run
 // per sample: 2.9 TB/s.)  Vector fields: 16-branch tiles (63 KB of LDS for obs at T = 34); scalar fields: 64-branch tiles.
-constexpr int kVecTile = 16;
+#ifndef FLAT_WAVES
+#define FLAT_WAVES 3
+#endif
+#ifndef FLAT_WIDE_TILES
+#define FLAT_WIDE_TILES 1      // 0: 16-branch tiles whatever the rollout's length (diagnostic)
+#endif
+constexpr int kVecTile = FLAT_WIDE_TILES ? 64 : 16;      // (16 at 34 steps of AntSafe shapes by the 64 KB rule below; 64 after a rollout of <= 8 steps)
 constexpr int kFlatRows = 64;
 
 struct FlatArgs {
@@ -929,10 +935,11 @@ struct FlatArgs {
 // one vector field of the tile: buffer -> LDS ([branch][step][dim]).  Steps go round-robin over the four waves, NU steps
 // per wave and pass, and every load of a pass is requested before the first LDS write: a workgroup pays the HBM latency
 // once per pass, not once per step (at T = 34 one pass covers the tile).
-template <int NU>
+template <int NU, int KV>
 __device__ __forceinline__ void flat_vec_in(float *tile, const float *src, int dim, int nb, int T, int lmax, size_t B, int lane,
                                             int wave, int tid) {
-  constexpr int KV = 2;                     // 16-byte loads per lane and step: runs of up to 512 floats
+  // KV 16-byte loads per lane and step: runs of up to 256 KV floats (2: 16-branch tiles of long rollouts; 8: the 64-branch
+  // tiles of short ones)
   const int run = nb * dim;                 // floats of the tile at one step: contiguous in the buffer
   const int c = (T - 1) * dim;
   // step t, element j = bl * dim + d  ->  tile[(bl * T + t) * dim + d] = tile[j + bl * c + t * dim]
@@ -946,21 +953,27 @@ __device__ __forceinline__ void flat_vec_in(float *tile, const float *src, int d
       d0[k] = jj - bl * dim;
       i0[k] = jj + bl * c;
     }
-    const bool two = run > 256;
+    const int kmax = (run + 255) >> 8;      // loads per lane that reach into the run (wave-uniform)
     for (int tb = wave; tb < lmax; tb += 4 * NU) {
       f32x4 v[NU][KV];
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         const int t = min(tb + 4 * u, T - 1);
         const float *st = src + (size_t)t * B * dim;
-        v[u][0] = *reinterpret_cast<const f32x4 *>(st + (j0[0] < run ? j0[0] : 0));
-        if (two) v[u][1] = *reinterpret_cast<const f32x4 *>(st + (j0[1] < run ? j0[1] : 0));
+        if constexpr (KV == 2) {     // (the long-rollout form exactly as it was: one flag, hoisted out of the loop)
+          v[u][0] = *reinterpret_cast<const f32x4 *>(st + (j0[0] < run ? j0[0] : 0));
+          if (kmax > 1) v[u][1] = *reinterpret_cast<const f32x4 *>(st + (j0[1] < run ? j0[1] : 0));
+        } else {
+#pragma unroll
+          for (int k = 0; k < KV; ++k)
+            if (k == 0 || k < kmax) v[u][k] = *reinterpret_cast<const f32x4 *>(st + (j0[k] < run ? j0[k] : 0));
+        }
       }
 #pragma unroll
       for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int k = 0; k < KV; ++k)
-          if (tb + 4 * u < lmax && j0[k] < run && (k == 0 || two)) {
+          if (tb + 4 * u < lmax && j0[k] < run && (k == 0 || k < kmax)) {
             float *q = tile + i0[k] + (tb + 4 * u) * dim;
 #pragma unroll
             for (int i = 0; i < 4; ++i) q[i + (d0[k] + i >= dim ? c : 0)] = v[u][k][i];
@@ -999,25 +1012,30 @@ __device__ __forceinline__ void flat_vec_out(const float *tile, float *dst, int 
   }
 }
 
+// SHORT: the rollout ended within 8 steps -- tiles of up to 64 branches through the 2-step x 8-load pass; else tiles of up to
+// 16 branches through the 9-step x 2-load pass (one instantiation of the kernel each: with both passes in one body the
+// long-rollout shapes lost 7 % of their flatten)
+template <bool SHORT>
 __device__ __forceinline__ void flatten_vec_body(const cmbpo_rollout_t &r, const int32_t *offs, const FlatArgs &fa, int vt, int Tt,
                                                  int blk) {
+  constexpr int VT_MAX = SHORT ? kVecTile : 16;
   // Tt = the steps the rollout took (<= r.T): no path is longer, so the tiles are laid out -- and the LDS sized -- for Tt
   // steps (an 'uncertainty' rollout that ended after 5 of 34 steps: 9 KB per workgroup instead of 63, eight workgroups
   // per CU instead of two)
   extern __shared__ float tile[];          // [vt][Tt][obs_dim], then [3][vt][Tt][act_dim]; vt <= kVecTile branches
-  __shared__ int lens[kVecTile], loffs[kVecTile + 1];
+  __shared__ int lens[VT_MAX], loffs[VT_MAX + 1];
   // (behind the tiles: output position inside the tile's block -> bl * Tt + t, vt * Tt entries)
   unsigned short *smap = reinterpret_cast<unsigned short *>(tile + (size_t)vt * Tt * max(r.obs_dim, 3 * r.act_dim));
   const int b0 = blk * vt;
   const int nb = min(r.B - b0, vt);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < kVecTile) lens[tid] = tid < nb ? r.len[b0 + tid] : 0;
-  if (tid <= kVecTile) loffs[tid] = offs[min(b0 + tid, r.B)];
+  if (tid < VT_MAX) lens[tid] = tid < nb ? r.len[b0 + tid] : 0;
+  if (tid <= VT_MAX) loffs[tid] = offs[min(b0 + tid, r.B)];
   __syncthreads();
   const int o0 = loffs[0], cnt = loffs[nb] - o0;
   if (cnt == 0) return;
   int lmax = 0;
-  for (int i = 0; i < nb; ++i) lmax = max(lmax, lens[i]);
+  for (int i = 0; i < nb; ++i) lmax = max(lmax, lens[i]);      // (broadcast reads, pipelined: cheaper than a shuffle tree)
   const size_t B = (size_t)r.B;
   const int T = Tt, D = r.obs_dim, A = r.act_dim;
   if (cnt != nb * T) {
@@ -1029,25 +1047,25 @@ __device__ __forceinline__ void flatten_vec_body(const cmbpo_rollout_t &r, const
   // 4 waves x NU steps per pass, every load of a pass in flight before the first LDS write: 9 covers T <= 36 in one pass; a
   // rollout that ended after a few steps ('uncertainty' mode) takes the 2-step form -- steps past the last are clamped
   // copies of it, and seven of nine were
-  auto body = [&](auto NUC) {
-    constexpr int NU = decltype(NUC)::value;
+  auto body = [&](auto NUC, auto KVC) {
+    constexpr int NU = decltype(NUC)::value, KV = decltype(KVC)::value;
     // obs (output 0)
-    flat_vec_in<NU>(tile, r.obs_buf + (size_t)b0 * D, D, nb, T, lmax, B, lane, wave, tid);
+    flat_vec_in<NU, KV>(tile, r.obs_buf + (size_t)b0 * D, D, nb, T, lmax, B, lane, wave, tid);
     __syncthreads();
     flat_vec_out(tile, fa.out[0] + (size_t)o0 * D, D, nb, T, cnt, o0, smap, tid);
     __syncthreads();
     // act (1), log_std (10), mu (11): three tiles side by side
     const size_t ts = (size_t)vt * T * A;
-    flat_vec_in<NU>(tile, r.act_buf + (size_t)b0 * A, A, nb, T, lmax, B, lane, wave, tid);
-    flat_vec_in<NU>(tile + ts, r.ls_buf + (size_t)b0 * A, A, nb, T, lmax, B, lane, wave, tid);
-    flat_vec_in<NU>(tile + 2 * ts, r.mu_buf + (size_t)b0 * A, A, nb, T, lmax, B, lane, wave, tid);
+    flat_vec_in<NU, KV>(tile, r.act_buf + (size_t)b0 * A, A, nb, T, lmax, B, lane, wave, tid);
+    flat_vec_in<NU, KV>(tile + ts, r.ls_buf + (size_t)b0 * A, A, nb, T, lmax, B, lane, wave, tid);
+    flat_vec_in<NU, KV>(tile + 2 * ts, r.mu_buf + (size_t)b0 * A, A, nb, T, lmax, B, lane, wave, tid);
     __syncthreads();
     flat_vec_out(tile, fa.out[1] + (size_t)o0 * A, A, nb, T, cnt, o0, smap, tid);
     flat_vec_out(tile + ts, fa.out[10] + (size_t)o0 * A, A, nb, T, cnt, o0, smap, tid);
     flat_vec_out(tile + 2 * ts, fa.out[11] + (size_t)o0 * A, A, nb, T, cnt, o0, smap, tid);
   };
-  if (T <= 8) body(std::integral_constant<int, 2>{});
-  else body(std::integral_constant<int, 9>{});
+  if constexpr (SHORT) body(std::integral_constant<int, 2>{}, std::integral_constant<int, FLAT_WIDE_TILES ? 8 : 2>{});
+  else body(std::integral_constant<int, 9>{}, std::integral_constant<int, 2>{});
 }
 
 // ROWS branches per workgroup: 64 (16 lanes x 16 bytes cover a step's row of the tile), or 16 for buffers too small to give
@@ -1397,10 +1415,12 @@ extern "C" int cmbpo_buffer_prepare(const cmbpo_rollout_t *r, int32_t *d_offsets
 // fields' (two launches of ~10 us each around 20-40 us of copying at the shipped configurations' 1e4 branches; the scalar tiles
 // fill the CUs the vector tiles leave).  Dynamic LDS: the larger of the two layouts.
 namespace {
-template <int ROWS>
-__global__ __launch_bounds__(256) void flatten_kernel(const cmbpo_rollout_t r, const int32_t *offs, const double *st, const FlatArgs fa,
+// (three waves per SIMD: the two load passes' registers sit at 168-169 VGPRs, the edge between three waves and two -- two cost
+// every shape but the short ragged one 14-35 % of its flatten)
+template <int ROWS, bool SHORT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FLAT_WAVES))) void flatten_kernel(const cmbpo_rollout_t r, const int32_t *offs, const double *st, const FlatArgs fa,
                                                       int vt, int Tt, int n_vec) {
-  if ((int)blockIdx.x < n_vec) flatten_vec_body(r, offs, fa, vt, Tt, (int)blockIdx.x);
+  if ((int)blockIdx.x < n_vec) flatten_vec_body<SHORT>(r, offs, fa, vt, Tt, (int)blockIdx.x);
   else flatten_scalar_body<ROWS>(r, offs, st, fa, Tt, (int)blockIdx.x - n_vec);
 }
 }  // namespace
@@ -1426,32 +1446,43 @@ extern "C" int cmbpo_buffer_flatten(const cmbpo_rollout_t *r, const int32_t *d_o
   // no path is longer than the steps the rollout took: tiles (and their LDS) are sized for those
   const int Tt = r->ptr > 0 ? r->ptr : 1;
   // branches per workgroup of the vector fields: as many as keep the [branch][step][dim] tile within 64 KB (two
-  // workgroups per CU; 16 at AntSafe shapes and 34 steps), fewer while the buffer has less than four tiles per CU
+  // workgroups per CU; 16 at AntSafe shapes and 34 steps, 64 after a rollout that ended within 8 steps), fewer while the
+  // buffer has less than four tiles per CU
   static const int vt_max = getenv("CMBPO_FLAT_VT") ? atoi(getenv("CMBPO_FLAT_VT")) : kVecTile;
-  int vt = vt_max < 1 ? 1 : (vt_max > kVecTile ? kVecTile : vt_max);
+  const int vt_cap = Tt <= 8 ? kVecTile : 16;     // (64-branch tiles only after short rollouts: the 2 x 8-load pass)
+  int vt = vt_max < 1 ? 1 : (vt_max > vt_cap ? vt_cap : vt_max);
   const int dtile = dmax > 3 * r->act_dim ? dmax : 3 * r->act_dim;     // obs alone, then act | log_std | mu side by side
   while (vt > 1 && (size_t)vt * Tt * dtile * sizeof(float) > 64 * 1024) vt >>= 1;
+  // ... and as keep a step's run of the tile (vt x dim floats) inside the 8 x 16 bytes per lane of the short rollouts' load
+  // pass (flat_vec_in; a longer run falls back to its element-wise loop)
+  if (FLAT_WIDE_TILES && Tt <= 8)
+    while (vt > 4 && vt * dmax > 2048) vt >>= 1;
   while (vt > 4 && cmbpo_ceil_div(r->B, vt) < 4 * n_cu) vt >>= 1;
   const int rows = cmbpo_ceil_div(r->B, kFlatRows) < 2 * n_cu ? 16 : kFlatRows;
   const size_t lds_v = (size_t)vt * Tt * dtile * sizeof(float) + (((size_t)vt * Tt * sizeof(unsigned short) + 15) & ~(size_t)15);
   const size_t lds_s = (size_t)8 * rows * (Tt + 1) * sizeof(float) + (size_t)rows * Tt * sizeof(unsigned short);
   CMBPO_REQUIRE(lds_v <= 150 * 1024 && lds_s <= 150 * 1024, "cmbpo_buffer_flatten: T = %d, dim = %d exceed the LDS tiles", Tt, dmax);
   const size_t lds = lds_v > lds_s ? lds_v : lds_s;
-  static size_t attr = 64 * 1024;
-  if (lds > attr) {
-    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(flatten_kernel<kFlatRows>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(flatten_kernel<16>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = lds;
-  }
+  const bool is_short = Tt <= 8;
   const int n_vec = cmbpo_ceil_div(r->B, vt);
-  if (rows == 16)
-    hipLaunchKernelGGL(flatten_kernel<16>, dim3(n_vec + cmbpo_ceil_div(r->B, 16)), dim3(256), lds, s, *r, d_offsets, d_stats, fa, vt, Tt,
-                       n_vec);
-  else
-    hipLaunchKernelGGL(flatten_kernel<kFlatRows>, dim3(n_vec + cmbpo_ceil_div(r->B, kFlatRows)), dim3(256), lds, s, *r, d_offsets,
-                       d_stats, fa, vt, Tt, n_vec);
+  static size_t attr[2][2] = {{64 * 1024, 64 * 1024}, {64 * 1024, 64 * 1024}};
+  auto launch = [&](auto kern, size_t &granted, int n_scalar) -> int {
+    if (lds > granted) {
+      CMBPO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      granted = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_vec + n_scalar), dim3(256), lds, s, *r, d_offsets, d_stats, fa, vt, Tt, n_vec);
+    return CMBPO_OK;
+  };
+  int rc;
+  if (rows == 16) {
+    rc = is_short ? launch(flatten_kernel<16, true>, attr[0][1], cmbpo_ceil_div(r->B, 16))
+                  : launch(flatten_kernel<16, false>, attr[0][0], cmbpo_ceil_div(r->B, 16));
+  } else {
+    rc = is_short ? launch(flatten_kernel<kFlatRows, true>, attr[1][1], cmbpo_ceil_div(r->B, kFlatRows))
+                  : launch(flatten_kernel<kFlatRows, false>, attr[1][0], cmbpo_ceil_div(r->B, kFlatRows));
+  }
+  if (rc) return rc;
   CMBPO_HIP_CHECK(hipGetLastError());
   return CMBPO_OK;
 }

@@ -214,3 +214,45 @@ def test_rollout_properties_at_config5_shard(hip_lib):
         assert bool(torch.isfinite(t_).all())
     assert set(np.unique(cost.cpu().numpy())) <= {0.0, 1.0}
     assert pool.n_alive == B and pool.size == 0
+
+
+@pytest.mark.parametrize("task,B,T", [("AntSafe-v2", 70001, 6), ("HumanoidSafe-v2", 66000, 9), ("HopperSafe-v2", 70000, 4),
+                                      ("AntSafe-v2", 70001, 12)])
+def test_get_after_a_short_ragged_rollout_matches_a_gather(hip_lib, task, B, T):
+    """ModelBuffer.get() after 'uncertainty' rollouts that end within a few steps, at sizes where the flatten takes its
+    64-branch tiles (<= 8 steps) and its 16-branch ones (11 steps): every one of the twelve outputs against a plain gather
+    from the [step][branch] buffers in branch-major order (buffers/modelbuffer.py:184-226)."""
+    _need_gpu()
+    import bench
+    from cmbpo_amd import synthetic
+    w = bench.build_world(0, task)
+    sampler, pool, env, policy = bench.build_hip(w, task, B, torch.device("cuda:0"), maxroll=T, mode="uncertainty")
+    start = synthetic.start_states(np.random.default_rng(11), B, task)
+    start_d = torch.from_numpy(start).cuda()
+    # a limit a little under the rollouts' own uncertainty: branches die over the first steps, at different ones
+    sampler.set_rollout_dkl(float(sampler.compute_dynamics_dkl(start_d[:5000], depth=3)) * 0.8)
+    sampler.reset(start_d)
+    while pool.n_alive > 0:
+        sampler.sample()
+    sampler.finish_all_paths()
+    lens = pool.t["len"].clone()
+    steps = int(lens.max())
+    assert 1 <= steps <= T - 1 and int(lens.min()) < steps            # ragged
+    raw = {k: pool.t[k].clone() for k in ("obs_buf", "act_buf", "mu_buf", "ls_buf", "adv_buf", "cadv_buf", "ret_buf",
+                                          "cret_buf", "logp_buf", "val_buf", "cval_buf", "cost_buf")}
+    res, diag = pool.get(as_tensors=True)
+    # sample p of the output = step t of branch b, branches in order, steps in order
+    b_idx = torch.repeat_interleave(torch.arange(B, device="cuda"), lens.long())
+    first = torch.cumsum(lens.long(), 0) - lens.long()
+    t_idx = torch.arange(b_idx.numel(), device="cuda") - first[b_idx]
+    n = int(lens.sum())
+    assert diag["poolm_batch_size"] == n == b_idx.numel()
+    g = lambda name: raw[name][t_idx, b_idx]
+    obs, act, adv, cadv, ret, cret, logp, val, cval, cost, ls, mu = res
+    for got, name in ((obs, "obs_buf"), (act, "act_buf"), (ret, "ret_buf"), (cret, "cret_buf"), (logp, "logp_buf"),
+                      (val, "val_buf"), (cval, "cval_buf"), (cost, "cost_buf"), (ls, "ls_buf"), (mu, "mu_buf")):
+        assert torch.equal(got, g(name)), name
+    a = g("adv_buf").double()
+    torch.testing.assert_close(adv.double(), (a - a.mean()) / (a.std(unbiased=False) + 1e-8), rtol=1e-4, atol=1e-5)
+    c = g("cadv_buf").double()
+    torch.testing.assert_close(cadv.double(), c - c.mean(), rtol=1e-4, atol=1e-5)

@@ -1,6 +1,6 @@
 """Dev probe: time of ModelBuffer.get()'s kernels (offsets / moments / flatten) after a full-size rollout, and the HBM
 rate of the flatten (algorithmic bytes: every stored float read once and written once).
-    python tools/probe_get.py [B] [mode]"""
+    python tools/probe_get.py [B] [task] [maxroll] [schedule|uncertainty] [dkl scale]"""
 import ctypes as C
 import os
 import sys
@@ -15,10 +15,14 @@ from cmbpo_amd import synthetic
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 task = sys.argv[2] if len(sys.argv) > 2 else "AntSafe-v2"
+maxroll = int(sys.argv[3]) if len(sys.argv) > 3 else bench.MAXROLL
+mode = sys.argv[4] if len(sys.argv) > 4 else "schedule"
 w = bench.build_world(0, task)
 dev = torch.device("cuda:0")
-sampler, pool, env, policy = bench.build_hip(w, task, B, dev)
+sampler, pool, env, policy = bench.build_hip(w, task, B, dev, maxroll=maxroll, mode=mode)
 start = torch.from_numpy(synthetic.start_states(np.random.default_rng(1), B, task)).to(dev)
+if mode == "uncertainty":
+    sampler.set_rollout_dkl(float(sampler.compute_dynamics_dkl(start[:5000], depth=5)) * (float(sys.argv[5]) if len(sys.argv) > 5 else 0.6))
 sampler.reset(start)
 while sampler.any_alive():
     sampler.sample()
@@ -52,6 +56,7 @@ outs = [torch.empty((n, d) if d else (n,), **f) for d in dims]
 ptrs = (C.c_void_p * 12)(*[o.data_ptr() for o in outs])
 us_fl = timed(lambda: pool._call("cmbpo_buffer_flatten", t["offsets"].data_ptr(), t["stats"].data_ptr(), ptrs))
 bytes_fl = 2.0 * 4.0 * n * (D + 3 * A + 8)
+print(f"B={B} {task} maxroll {maxroll} {mode}: steps taken {pool.ptr}")
 print(f"samples {n}: offsets {us_off:.1f} us, moments pass0 {us_m0:.1f} us, pass2 {us_m2:.1f} us, flatten {us_fl:.1f} us "
       f"= {bytes_fl / us_fl / 1e6:.2f} TB/s ({bytes_fl / 1e6:.0f} MB algorithmic)")
 print(f"one-GPU path: prepare (scan + both moment passes, two launches) {us_prep:.1f} us; with flatten {us_prep + us_fl:.1f} us")

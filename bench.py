@@ -543,7 +543,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    comm = Comm.init_from_env("nccl")
+    comm = Comm.init_from_env(None)      # nccl (= RCCL) with a GPU per rank, gloo when ranks share a card (dist.py)
     comm.device = device
     rank, world = comm.rank, comm.world
     if world != args.gpus:      # never fall back to fewer ranks than asked for

@@ -39,7 +39,11 @@ class Comm:
         if world > 1 and not td.is_initialized():
             backend = os.environ.get("CMBPO_DIST_BACKEND", backend)
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # nccl (= RCCL) wants a GPU per rank of this node ("Duplicate GPU detected" otherwise): ranks that share
+                # a card -- a rehearsal of N ranks on a one-GPU box -- reduce through gloo and host staging instead
+                n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+                local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+                backend = "nccl" if n_dev >= max(local_world, 1) else "gloo"
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             td.init_process_group(backend=backend)
         return Comm()

@@ -43,6 +43,7 @@ SIGNATURES = {
     "cmbpo_mlp_create": (_i, [C.POINTER(_p), _i, _i, _i, _i, _i, _i]),
     "cmbpo_mlp_destroy": (None, [_p]),
     "cmbpo_mlp_load": (_i, [_p] * 13),
+    "cmbpo_mlp_load_policy_flat": (_i, [_p, _p, _p]),
     "cmbpo_ens_forward": (_i, [_p, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p]),
     "cmbpo_ens_predict_mean": (_i, [_p, _p, _i, _p, _p, _i, _p, _p]),
     "cmbpo_critic_pair_supported": (_i, [_p, _p]),

@@ -35,8 +35,10 @@ class GaussianActor:
         self.params = None
         self.version = 0      # bumped by set_params so dependants can re-sync lazily
 
-    def set_params(self, params):
-        """params: list of 7 arrays, or one flat vector in the same order (trust_region.py:21-25)."""
+    def set_params(self, params, device_flat=None):
+        """params: list of 7 arrays, or one flat vector in the same order (trust_region.py:21-25).  device_flat: the same
+        flat vector as a float32 device tensor (the update's accepted parameters): the rollout handle is then packed from
+        it on the device, `params` only refreshes the host copy."""
         if not isinstance(params, (list, tuple)):
             flat = np.asarray(params, dtype=np.float32).reshape(-1)
             assert flat.size == self.n_params
@@ -47,7 +49,14 @@ class GaussianActor:
         self.params = [np.ascontiguousarray(p, dtype=np.float32).reshape(s) for p, s in zip(params, self.shapes)]
         w0, b0, w1, b1, w2, b2, ls = self.params
         self.version += 1
+        if device_flat is not None and getattr(self, "_loaded_once", False):
+            assert device_flat.dtype == torch.float32 and device_flat.numel() == self.n_params and device_flat.is_contiguous()
+            with torch.cuda.device(self.mlp.device):
+                _lib.check(_lib.lib().cmbpo_mlp_load_policy_flat(self.mlp.handle, device_flat.data_ptr(), _lib.current_stream()),
+                           "cmbpo_mlp_load_policy_flat")
+            return
         self.mlp.load([w0[None], w1[None], w2[None]], [b0[None], b1[None], b2[None]], log_std=ls)
+        self._loaded_once = True
 
     def get_flat_params(self):
         return np.concatenate([p.reshape(-1) for p in self.params]).astype(np.float32)
@@ -171,7 +180,8 @@ class CPOPolicy:
         self.logger.store(LossPi=pre["LossPi"], SurrCost=pre["SurrCost"], SurrAdv=pre["SurrAdv"],
                           Entropy=pre["Entropy"])
         # the accepted (or restored) parameters now live in ops; mirror them into the rollout actor
-        self.actor.set_params(info["params"] if info.get("params") is not None else self.ops.get_params())
+        self.actor.set_params(info["params"] if info.get("params") is not None else self.ops.get_params(),
+                              device_flat=self.ops.params)
         self._ops_version = self.actor.version
         deltas = {k + "Delta": post[k] - pre[k] for k in ("LossPi", "SurrCost", "SurrAdv")}
         self.logger.store(KL=post["KL"], **deltas)

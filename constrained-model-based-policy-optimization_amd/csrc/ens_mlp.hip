@@ -673,6 +673,59 @@ extern "C" int cmbpo_mlp_load(cmbpo_mlp_t *m, const float *h_w0, const float *h_
 }
 
 namespace {
+// One flat parameter vector of a Gaussian policy on the device -> the handle's packs (the layout of pack_weights):
+// flat = W0[in,H] | b0[H] | W1[H,H] | b1[H] | W2[H,O] | b2[O] | log_std[O]  (get_vars('pi'), network/ac_network.py:35-36)
+struct FlatLoadArgs {
+  int I, H, O, in_pad, o_tiles;
+  size_t off_wp0, off_wp1, off_wp2, off_b0, off_b1, off_b2, off_log_std;
+  int n0, n1, n2;        // floats of the three packs
+};
+__global__ void policy_flat_load_kernel(const float *flat, float *blob, FlatLoadArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int oW0 = 0, ob0 = a.I * a.H, oW1 = ob0 + a.H, ob1 = oW1 + a.H * a.H, oW2 = ob1 + a.H, ob2 = oW2 + a.H * a.O,
+            ols = ob2 + a.O;
+  auto pack = [&](int i, int K, int N, int k_pad, int src_off, size_t dst_off) {
+    const int s = i & 3, lane = (i >> 2) & 63, kg = k_pad / 8, g = (i >> 8) % kg, nt = (i >> 8) / kg;
+    const int n = nt * 32 + (lane & 31), k = 8 * g + 4 * (lane >> 5) + s;
+    blob[dst_off + i] = (k < K && n < N) ? flat[src_off + (size_t)k * N + n] : 0.0f;
+  };
+  int i = idx;
+  if (i < a.n0) { pack(i, a.I, a.H, a.in_pad, oW0, a.off_wp0); return; }
+  i -= a.n0;
+  if (i < a.n1) { pack(i, a.H, a.H, a.H, oW1, a.off_wp1); return; }
+  i -= a.n1;
+  if (i < a.n2) { pack(i, a.H, a.O, a.H, oW2, a.off_wp2); return; }
+  i -= a.n2;
+  if (i < a.H) { blob[a.off_b0 + i] = flat[ob0 + i]; return; }
+  i -= a.H;
+  if (i < a.H) { blob[a.off_b1 + i] = flat[ob1 + i]; return; }
+  i -= a.H;
+  if (i < a.o_tiles * 32) { blob[a.off_b2 + i] = i < a.O ? flat[ob2 + i] : 0.0f; return; }
+  i -= a.o_tiles * 32;
+  if (i < a.O) blob[a.off_log_std + i] = flat[ols + i];
+}
+}  // namespace
+
+extern "C" int cmbpo_mlp_load_policy_flat(cmbpo_mlp_t *m, const float *d_flat, void *stream) {
+  CMBPO_REQUIRE(m != nullptr && d_flat != nullptr, "cmbpo_mlp_load_policy_flat: NULL argument");
+  CMBPO_REQUIRE(m->head == CMBPO_HEAD_GAUSS_PI && m->ensemble == 1,
+                "cmbpo_mlp_load_policy_flat: a single Gaussian-policy network (head %d, ensemble %d)", m->head, m->ensemble);
+  if (!m->loaded) { cmbpo_set_error("cmbpo_mlp_load_policy_flat: load the handle once through cmbpo_mlp_load first"); return CMBPO_ESTATE; }
+  CMBPO_REQUIRE(!m->has_in_scaler && !m->has_out_scaler, "cmbpo_mlp_load_policy_flat: the handle has scalers");
+  FlatLoadArgs a;
+  a.I = m->in_dim; a.H = m->hidden; a.O = m->o_width; a.in_pad = m->in_pad; a.o_tiles = m->o_tiles;
+  a.off_wp0 = m->off_wp0; a.off_wp1 = m->off_wp1; a.off_wp2 = m->off_wp2;
+  a.off_b0 = m->off_b0; a.off_b1 = m->off_b1; a.off_b2 = m->off_b2; a.off_log_std = m->off_log_std;
+  a.n0 = (a.H / 32) * (a.in_pad / 8) * 256; a.n1 = (a.H / 32) * (a.H / 8) * 256; a.n2 = a.o_tiles * (a.H / 8) * 256;
+  const int total = a.n0 + a.n1 + a.n2 + 2 * a.H + a.o_tiles * 32 + a.O;
+  ++m->pack_version;        // (the f16 images of the rollout actor follow the packs' version)
+  hipLaunchKernelGGL(policy_flat_load_kernel, dim3(cmbpo_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, d_flat,
+                     m->d_blob, a);
+  CMBPO_HIP_CHECK(hipGetLastError());
+  return CMBPO_OK;
+}
+
+namespace {
 
 int g_dispatch_mode = 0;   // 0: one workgroup per item (hardware dispatch), 1: persistent static, 2: persistent dynamic
 int *g_work_counter = nullptr;

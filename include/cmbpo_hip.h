@@ -114,6 +114,15 @@ int cmbpo_mlp_load(cmbpo_mlp_t *m, const float *h_w0, const float *h_b0,
                    const float *h_out_var, const float *h_log_std,
                    void *stream);
 
+/* A Gaussian policy's parameters as ONE flat device vector in the order of
+ * get_vars('pi') (network/ac_network.py:35-36, the order trust_region.py:21-25
+ * assigns them in): W0[in,H] | b0 | W1[H,H] | b1 | W2[H,out] | b2 | log_std.
+ * The trust-region update leaves the accepted parameters on the device
+ * (policies/cpo_policy.py:278-300); this packs them into a handle that was
+ * loaded once through cmbpo_mlp_load (one network, GAUSS_PI head, no scalers)
+ * without a trip through the host. */
+int cmbpo_mlp_load_policy_flat(cmbpo_mlp_t *m, const float *d_flat, void *stream);
+
 /* PE.predict_ensemble, 2-D input path (models/pens/pe.py:688-697 ->
  * _compile_outputs(scale_output=True) :789-838 -> FC.compute_output_tensor
  * models/pens/fc.py:74-95 -> TensorStandardScaler models/pens/utils.py:156-187).

@@ -216,6 +216,24 @@ def test_update_policy_matches_oracle(hip_lib, name, cost_p, cadv_scale, cost_li
         assert k in st, k
     if ref["accepted"]:
         assert float(st["KL"]) <= 0.01 * 1.05
+    # the rollout actor was re-packed ON THE DEVICE from the parameters the update left there (cmbpo_mlp_load_policy_flat):
+    # the same forward, bit for bit, as an actor that loads the same parameters through the host
+    from cmbpo_amd.cpo_policy import GaussianActor
+    fresh = GaussianActor(D, A, (hidden, hidden), device="cuda:0")
+    fresh.set_params(new_params)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    obs_t = torch.randn(300, D, device="cuda", generator=g)
+    eps_t = torch.randn(300, A, device="cuda", generator=g)
+
+    def fwd(actor):
+        out = {"pi": torch.empty(300, A, device="cuda"), "logp_pi": torch.empty(300, device="cuda"),
+               "mu": torch.empty(300, A, device="cuda"), "log_std": torch.empty(300, A, device="cuda")}
+        actor.forward_device(obs_t, eps_t, out)
+        return out
+    o_upd, o_host = fwd(pol.actor), fwd(fresh)
+    for k in o_upd:
+        assert torch.equal(o_upd[k], o_host[k]), k
+    np.testing.assert_array_equal(np.asarray(pol.ops.get_params()), new_params)
 
 
 def test_cg_solve_graph_matches_eager_loop(hip_lib):
